@@ -1,0 +1,196 @@
+"""Pin the CPU oracle (oracle/darknet_ref.py) against fixtures captured from the REAL reference.
+
+The fixtures under tests/golden/ were written by tests/golden/make_golden.py, which imports
+/root/reference (uguryagmur/RealTimeObjectDetection) in the build container.  These tests are CPU
+only and run everywhere; the ``reference``-marked ones additionally compare against the live
+reference when it is mounted.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from realtimeobjectdetection_amd import cfgs, synth
+from realtimeobjectdetection_amd.cfg import parse_cfg_text, parse_cfg, build_ir
+from oracle import darknet_ref as O
+
+NETS = {"yolov3-tiny": cfgs.yolov3_tiny_cfg, "yolov3": cfgs.yolov3_cfg}
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---------------------------------------------------------------- G1 / G2: cfg -> IR, weights
+@pytest.mark.parametrize("net", list(NETS))
+def test_ir_matches_reference_modules(golden_dir, net):
+    g = json.load(open(os.path.join(golden_dir, f"ir_{net}.json")))
+    ir = build_ir(parse_cfg_text(NETS[net]()), 416)
+    assert len(ir.layers) == len(g["layers"])
+    for L, R in zip(ir.layers, g["layers"]):
+        assert L.type == R["type"], L.index
+        if L.type == "convolutional":
+            assert (L.cin, L.cout, L.size, L.stride, L.pad) == (R["cin"], R["cout"], R["size"], R["stride"], R["pad"])
+            assert L.bn == R["bn"] and L.leaky == R["leaky"] and (not L.bn) == R["bias"]
+        elif L.type == "yolo":
+            assert [list(a) for a in L.anchors] == R["anchors"] and L.classes == R["classes"]
+        elif L.type == "route":
+            assert list(L.srcs) == [a if a > 0 else L.index + a for a in R["layers"]]
+        elif L.type == "shortcut":
+            assert L.srcs == (L.index - 1, L.index + R["frm"])
+        elif L.type == "maxpool":
+            assert (L.size, L.stride) == (R["size"], R["stride"])
+    assert ir.n_weights == g["n_weight_floats"]
+    assert ir.n_weights == {"yolov3": 62001757, "yolov3-tiny": 8858734}[net]
+
+
+def test_rows_and_flops():
+    # SURVEY.md §8 a / BASELINE.md §2
+    for net, res, rows, gflop in (("yolov3", 608, 22743, 140.692), ("yolov3", 416, 10647, 65.864),
+                                  ("yolov3-tiny", 416, 2535, 5.565)):
+        ir = build_ir(parse_cfg_text(NETS[net]()), res)
+        assert ir.total_rows == rows
+        assert abs(ir.conv_flops / 1e9 - gflop) < 5e-3 * gflop, ir.conv_flops / 1e9
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("net", list(NETS))
+def test_generated_cfg_equals_reference_cfg(net):
+    ref_blocks = parse_cfg(f"/root/reference/cfg/{net}.cfg")
+    gen_blocks = parse_cfg_text(NETS[net]())
+    assert len(ref_blocks) == len(gen_blocks)
+    used = {"convolutional": ("batch_normalize", "filters", "size", "stride", "pad", "activation"),
+            "shortcut": ("from",), "route": ("layers",), "upsample": ("stride",),
+            "maxpool": ("size", "stride"), "yolo": ("mask", "anchors", "classes", "num")}
+    for r, g in zip(ref_blocks[1:], gen_blocks[1:]):
+        assert r["type"] == g["type"]
+        for k in used[r["type"]]:
+            assert (k in r) == (k in g)
+            if k in r:
+                assert r[k].replace(" ", "") == g[k].replace(" ", ""), (r, g)
+
+
+def test_weights_file_roundtrip(tmp_path):
+    ir = build_ir(parse_cfg_text(cfgs.yolov3_tiny_cfg()), 416)
+    w = synth.synth_weights(ir)
+    p = synth.write_weights_file(str(tmp_path / "t.weights"), w, seen=77)
+    assert os.path.getsize(p) == 20 + 4 * 8858734
+    h, w2 = synth.read_weights_file(p)
+    assert h[3] == 77 and np.array_equal(w, w2)
+
+
+# ---------------------------------------------------------------- G3 / G4: forward
+FWD_CASES = [("yolov3-tiny", 416, 1), ("yolov3-tiny", 608, 2), ("yolov3", 416, 2), ("yolov3", 608, 1)]
+
+
+def oracle_forward(net, res, B, keep_layers=False):
+    m = O.RefDarknet(NETS[net](), res)
+    m.load_weight_stream(synth.synth_weights(m.ir))
+    x = torch.from_numpy(synth.synth_frames(B, res))
+    with torch.no_grad():
+        return m, m.forward(x, keep_layers=keep_layers)
+
+
+@pytest.mark.parametrize("net,res,B", FWD_CASES)
+def test_oracle_forward_bit_identical_to_reference(golden_dir, net, res, B):
+    g = _load(golden_dir, f"fwd_{net}_{res}_b{B}.npz")
+    m, (y, outs) = oracle_forward(net, res, B, keep_layers=True)
+    y = y.numpy()
+    assert y.shape[1] == int(g["n_rows"])
+    rows = y[:, ::int(g["row_stride"]), :]
+    assert np.array_equal(rows, g["rows"])                 # same ATen ops -> bit identical
+    for i in range(len(m.ir.layers)):
+        flat = outs[i].numpy().reshape(-1)
+        assert np.array_equal(flat[g["layer_sample_idx"][i]], g["layer_samples"][i]), f"layer {i}"
+    d = O.write_results(torch.from_numpy(y), 80, 0.6, 0.5)
+    gd = _load(golden_dir, f"det_{net}_{res}_b{B}.npz")["det"]
+    assert np.array_equal(d.numpy(), gd)
+
+
+# ---------------------------------------------------------------- G5: head decode
+HEAD_ANCHORS = {13: [(116, 90), (156, 198), (373, 326)], 26: [(30, 61), (62, 45), (59, 119)],
+                52: [(10, 13), (16, 30), (33, 23)], 19: [(116, 90), (156, 198), (373, 326)],
+                38: [(30, 61), (62, 45), (59, 119)], 76: [(10, 13), (16, 30), (33, 23)]}
+
+
+def head_raw_inputs():
+    """Regenerates the raw head tensors of make_golden.py (same seed, same order)."""
+    rng = np.random.Generator(np.random.PCG64(555))
+    out = {}
+    for G in HEAD_ANCHORS:
+        out[G] = rng.standard_normal((2, 255, G, G), dtype=np.float32) * np.float32(1.5)
+    return out
+
+
+def test_oracle_head_decode(golden_dir):
+    g = _load(golden_dir, "head_decode.npz")
+    raws = head_raw_inputs()
+    for G, anchors in HEAD_ANCHORS.items():
+        res = 416 if G in (13, 26, 52) else 608
+        step = int(g[f"step_{G}"])
+        dec = O.predict_transform(torch.from_numpy(raws[G]), res, anchors, 80).numpy()
+        assert np.array_equal(dec[:, ::step], g[f"dec_{G}"]), G
+        dect = O.predict_transform(torch.from_numpy(raws[G]), res, anchors, 80, train=True).numpy()
+        assert np.array_equal(dect[:, ::step], g[f"dectrain_{G}"]), G
+
+
+# ---------------------------------------------------------------- G6: write_results
+NMS_SYNTH = {"synth_b2_n2535": dict(batch=2, n=2535, classes=80, res=416, seed=2024),
+             "synth_b8_n10647": dict(batch=8, n=10647, classes=80, res=416, seed=2025),
+             "synth_b3_n22743": dict(batch=3, n=22743, classes=80, res=608, seed=2026),
+             "synth_dense": dict(batch=2, n=3000, classes=80, res=416, seed=2027, obj_mu=0.5, obj_sigma=1.0),
+             "synth_c20": dict(batch=2, n=2000, classes=20, res=416, seed=2028, obj_mu=-2.0)}
+NMS_EDGE = ["edge_none", "edge_single", "edge_eqconf", "edge_identical", "edge_zeroscore",
+            "edge_allzeroscore", "edge_oneclass"]
+
+
+def nms_case_input(g, tag):
+    if tag in NMS_SYNTH:
+        return synth.synth_predictions(**NMS_SYNTH[tag])
+    return g[f"{tag}_in"]
+
+
+def check_nms_result(r, g, tag):
+    if int(g[f"{tag}_isint"]):
+        assert isinstance(r, int) and r == 0
+    else:
+        assert not isinstance(r, int)
+        r = r.cpu().numpy() if isinstance(r, torch.Tensor) else r
+        assert r.shape == g[f"{tag}_out"].shape, (tag, r.shape, g[f"{tag}_out"].shape)
+        assert r.dtype == np.float32
+        assert np.array_equal(r, g[f"{tag}_out"]), tag                 # bit exact incl. order
+
+
+@pytest.mark.parametrize("tag", list(NMS_SYNTH) + NMS_EDGE)
+def test_oracle_write_results(golden_dir, tag):
+    g = _load(golden_dir, "nms.npz")
+    conf, thr, ncls = g[f"{tag}_args"]
+    r = O.write_results(torch.from_numpy(nms_case_input(g, tag)), int(ncls), float(conf), float(thr))
+    check_nms_result(r, g, tag)
+
+
+def test_oracle_iou_and_mask(golden_dir):
+    g = _load(golden_dir, "iou.npz")
+    b = g["boxes"]
+    assert np.array_equal(O.bbox_iou_np(b[:1], b[1:]), g["iou"])
+    t = torch.from_numpy(synth.synth_predictions(1, 64, 80, 416, seed=5))
+    cm = O.confidence_mask(t, 0.02).numpy()
+    assert cm.astype(np.float64).sum() == float(g["cm_sum"])
+    assert int((cm[0, :, 4] != 0).sum()) == int(g["cm_nnz_rows"])
+
+
+# ---------------------------------------------------------------- live reference (build container)
+@pytest.mark.reference
+def test_oracle_vs_live_reference_write_results():
+    import sys, types
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, "/root/reference")
+    from src.util import write_results as ref_wr
+    for seed, B, N, conf, thr in ((31, 2, 1500, 0.5, 0.4), (32, 1, 4000, 0.7, 0.6), (33, 3, 800, 0.3, 0.5)):
+        p = synth.synth_predictions(B, N, 80, 416, seed=seed, obj_mu=-2.5)
+        a = ref_wr(torch.from_numpy(p.copy()), 80, conf, thr)
+        b = O.write_results(torch.from_numpy(p), 80, conf, thr)
+        assert np.array_equal(a.numpy(), b.numpy())
