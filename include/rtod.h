@@ -1,0 +1,138 @@
+/*
+ * rtod.h — C ABI of librtod.so: the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (uguryagmur/RealTimeObjectDetection) is pure Python and has no FFI layer; its
+ * boundary for this path is the Python API of src/darknet.py and src/util.py.  The host layer
+ * in realtimeobjectdetection_amd/{darknet,util}.py keeps that API and binds the entry points
+ * below through ctypes (INTEGRATION.md shows the stub).  Each entry point names the reference
+ * interface it replaces (file:line into /root/reference).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative rtod_status; it never throws and never
+ *    synchronises the device unless its comment says so;  rtod_last_error() returns the message
+ *    of the calling thread's last failure;
+ *  - "dev" pointers are device (HBM) addresses owned by the caller (torch.Tensor.data_ptr());
+ *    kernels are enqueued on the caller-supplied hipStream_t (void*; 0 = default stream);
+ *  - a plan is not thread-safe; distinct plans are independent;
+ *  - all tensors are float32.  Activations inside a plan are NHWC; the API edges keep the
+ *    reference's layouts (input NCHW [B,3,H,W], predictions [B,N,5+C], detections [D,8]).
+ */
+#ifndef RTOD_H
+#define RTOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtod_status {
+    RTOD_OK = 0,
+    RTOD_E_ARG = -1,     /* bad argument / shape */
+    RTOD_E_HIP = -2,     /* HIP runtime error (message has hipGetErrorString) */
+    RTOD_E_CFG = -3,     /* cfg grammar / unknown block (reference: src/darknet.py:524-526 asserts) */
+    RTOD_E_STATE = -4,   /* call order (e.g. forward before load_weights) */
+    RTOD_E_SIZE = -5     /* weight stream too short (reference: view_as raises, src/darknet.py:348) */
+} rtod_status;
+
+typedef struct rtod_plan rtod_plan;
+
+typedef struct rtod_plan_info {
+    int32_t n_layers;          /* cfg blocks after [net] (107 for yolov3, 24 for tiny) */
+    int32_t n_launches;        /* kernels enqueued by one rtod_forward */
+    int32_t height, width, max_batch;
+    int32_t total_rows;        /* N of the [B,N,5+C] output (22743 @608) */
+    int32_t attrs;             /* 5 + classes */
+    int64_t n_weight_floats;   /* floats a .weights payload must hold */
+    int64_t conv_flops_per_frame;   /* 2*MACs of the direct convolutions (SURVEY.md §8 d) */
+    int64_t arena_bytes;       /* activation arena the plan allocates for max_batch */
+    int64_t packed_weight_bytes;
+} rtod_plan_info;
+
+typedef struct rtod_launch_info {
+    int32_t layer;             /* cfg layer index this launch implements (fused layers: the conv) */
+    int32_t kind;              /* 0 conv-igemm, 1 input-pack, 2 upsample, 3 add, 4 maxpool, 5 decode, 6 copy */
+    int32_t variant;           /* conv tile variant id (see rtod_conv_variant_name) */
+    int32_t ksize, stride, cin, cout, hout, wout;
+    int32_t fused_residual, fused_decode;
+    int64_t flops_per_frame;   /* algorithmic 2*MACs (0 for non-conv launches) */
+    int64_t bytes_per_frame;   /* algorithmic bytes: input once + output once (+ residual) */
+    int64_t weight_bytes;      /* read once per launch */
+} rtod_launch_info;
+
+int rtod_version(void);
+/* Copies the calling thread's last error message (NUL-terminated, truncated to len). */
+int rtod_last_error(char* buf, size_t len);
+/* Number of HIP devices visible; does not initialise a device context. */
+int rtod_device_count(int* out);
+
+/* ---- plan = Darknet(cfg) ------------------------------------------------------------------
+ * replaces Darknet.__init__ -> parse_cfg + create_modules   src/darknet.py:176-189, 412-603
+ * Parses the cfg text (same grammar), resolves shapes for [*,3,height,width], plans NHWC buffers
+ * (zero-copy route concat, fused shortcut / head decode) and the launch list.  Host-only: no
+ * device memory is touched until rtod_plan_load_weights. */
+int rtod_plan_create(const char* cfg_text, size_t len, int height, int width, int max_batch,
+                     int device, rtod_plan** out);
+int rtod_plan_destroy(rtod_plan* plan);
+int rtod_plan_get_info(const rtod_plan* plan, rtod_plan_info* out);
+int rtod_plan_get_launch(const rtod_plan* plan, int index, rtod_launch_info* out);
+/* JSON description of the resolved layer IR (tests compare it with the Python IR / reference). */
+int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* needed);
+const char* rtod_conv_variant_name(int variant);
+
+/* replaces Darknet.load_weights                              src/darknet.py:316-410
+ * `w` is the float payload of a Darknet .weights file (after the 5xint32 header), host memory:
+ * per convolutional block [bn.bias, bn.weight, running_mean, running_var] or [conv.bias], then
+ * conv.weight (OIHW).  Folds eval-mode BatchNorm (eps 1e-5) into the conv, packs K-major panels,
+ * allocates device memory on first call and uploads.  Synchronises the device. */
+int rtod_plan_load_weights(rtod_plan* plan, const float* w, size_t n_floats);
+
+/* replaces Darknet.forward                                   src/darknet.py:199-303
+ * x_dev: [batch,3,H,W] NCHW float32; out_dev: [batch,N,5+C] (new contiguous tensor in the
+ * reference; here caller-allocated).  batch <= max_batch.  Enqueues only. */
+int rtod_forward(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream);
+/* Same, with a hipEvent pair around every launch (recorded on `stream`); synchronises and
+ * writes the per-launch durations in ms to launch_ms[n_launches] (host).  For bench/roofline. */
+int rtod_forward_timed(rtod_plan* plan, const float* x_dev, int batch, float* out_dev,
+                       void* stream, float* launch_ms);
+/* replaces `with model.train_mode():`                       src/darknet.py:305-314
+ * train != 0: heads apply only the sigmoids (TRAIN=True in predict_transform, util.py:211). */
+int rtod_plan_set_train_decode(rtod_plan* plan, int train);
+/* Debug/test: keep != 0 disables liveness-based arena reuse so that every layer's output is still
+ * intact after a forward (for rtod_plan_read_layer).  Call before rtod_plan_load_weights. */
+int rtod_plan_set_keep_all_layers(rtod_plan* plan, int keep);
+/* Debug/test: copies layer `layer`'s output (NHWC view -> dense NCHW float32) to out_dev
+ * [batch,C,H,W] after a forward; enqueues on stream. */
+int rtod_plan_layer_shape(const rtod_plan* plan, int layer, int* c, int* h, int* w);
+int rtod_plan_read_layer(rtod_plan* plan, int layer, int batch, float* out_dev_nchw, void* stream);
+
+/* replaces predict_transform                                 src/util.py:175-239
+ * raw_dev [batch, A*attrs, G, G] NCHW -> out_dev [batch, G*G*A, attrs]; anchors = A (w,h) pairs
+ * in input pixels (host); train != 0 applies only the three sigmoids. */
+int rtod_predict_transform(const float* raw_dev, int batch, int attrs, int grid, int n_anchors,
+                           const float* anchors_wh, int inp_dim, int train, float* out_dev,
+                           void* stream);
+
+/* replaces confidence_mask                                   src/util.py:106-117 */
+int rtod_confidence_mask(const float* pred_dev, int64_t rows, int attrs, float confidence,
+                         float* out_dev, void* stream);
+/* replaces bbox_iou (one box vs k boxes, row stride in floats) src/util.py:120-153 */
+int rtod_bbox_iou(const float* box1_dev, const float* boxes_dev, int k, int row_stride,
+                  float* iou_dev, void* stream);
+
+/* replaces write_results                                     src/util.py:242-346
+ * pred_dev [batch,n,5+num_class].  Writes detections rows [img,x1,y1,x2,y2,obj,score,cls] to
+ * out_dev[cap][8] in the reference's order (image asc, class asc, objectness desc) and
+ * counts_dev[0] = D (may exceed cap: then only cap rows were written), counts_dev[1] = number of
+ * candidate rows (obj > conf) over the batch, counts_dev[2..2+batch) = detections per image.
+ * Workspace: rtod_write_results_workspace(batch, n) bytes of device memory.  Enqueues only. */
+int rtod_write_results_workspace(int batch, int n, size_t* bytes);
+int rtod_write_results(const float* pred_dev, int batch, int n, int num_class, float confidence,
+                       float nms_conf, float* out_dev, int cap, int32_t* counts_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOD_H */

@@ -1,0 +1,245 @@
+// Bandwidth-bound helper kernels of the Darknet forward (gfx950): input NCHW->NHWC pack, bilinear x2
+// upsample, stand-alone shortcut add, max-pool, channel copy, NHWC->NCHW read-back, stand-alone head
+// decode, confidence mask, IoU.  All are HBM-bound elementwise work: one float4 (16 B) per lane
+// along the channel axis wherever the layout allows, grid capped at ~2048 blocks + grid stride.
+#include "rtod_internal.h"
+
+namespace rtod {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(int64_t work, int block) {
+    int64_t g = (work + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// input pack: x [B,C,H,W] (NCHW, C=3) -> [B,H,W,Cp] with channels C..Cp-1 zero.  The stem conv then
+// runs through the generic implicit-GEMM with Cin = Cp = 4 (16-B pixel = one float4 gather).
+__global__ void pack_input_kernel(const float* __restrict__ x, int B, int C, int H, int W,
+                                  float* __restrict__ out, int Cp) {
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t hw = (int64_t)H * W;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = p / hw, r = p - b * hw;
+        const float* src = x + b * C * hw + r;
+        for (int c0 = 0; c0 < Cp; c0 += 4) {
+            f32x4 v;
+            v[0] = c0 + 0 < C ? src[(c0 + 0) * hw] : 0.f;
+            v[1] = c0 + 1 < C ? src[(c0 + 1) * hw] : 0.f;
+            v[2] = c0 + 2 < C ? src[(c0 + 2) * hw] : 0.f;
+            v[3] = c0 + 3 < C ? src[(c0 + 3) * hw] : 0.f;
+            *reinterpret_cast<f32x4*>(out + p * Cp + c0) = v;
+        }
+    }
+}
+
+int launch_pack_input(const float* x, int B, int C, int H, int W, float* out, int Cp, hipStream_t s) {
+    if (!x || !out || Cp % 4 || Cp < C) { set_error("pack_input: bad args"); return RTOD_E_ARG; }
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, s, x, B, C, H, W, out, Cp);
+    return hip_fail(hipGetLastError(), "pack_input launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear x2, align_corners=False (reference: nn.Upsample(scale_factor=2, mode="bilinear"),
+// src/darknet.py:587-593).  src = (dst+0.5)/2-0.5 clamped at 0; weights are
+// exactly {1,0} on the borders and {0.25,0.75} inside.  Evaluated as wy0*(wx0*a+wx1*b)+wy1*(wx0*c+wx1*d),
+// ATen's separable order.
+__device__ __forceinline__ void up_coord(int o, int n, int& i0, int& i1, float& w1) {
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+__global__ void upsample2x_kernel(View in, View out, int B) {
+    const int C4 = in.C / 4;
+    const int64_t total = (int64_t)B * out.H * out.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        int64_t p = t / C4;
+        const int ox = (int)(p % out.W); p /= out.W;
+        const int oy = (int)(p % out.H);
+        const int b = (int)(p / out.H);
+        int y0, y1, x0, x1; float wy1, wx1;
+        up_coord(oy, in.H, y0, y1, wy1);
+        up_coord(ox, in.W, x0, x1, wx1);
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        const float* base = in.base + in.coff + c;
+        const int64_t rb = (int64_t)b * in.H;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((rb + y0) * in.W + x0) * in.ldc);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((rb + y0) * in.W + x1) * in.ldc);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((rb + y1) * in.W + x0) * in.ldc);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((rb + y1) * in.W + x1) * in.ldc);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            r[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+        *reinterpret_cast<f32x4*>(out.base + out.coff + c + (((int64_t)b * out.H + oy) * out.W + ox) * out.ldc) = r;
+    }
+}
+
+static bool view_ok4(const View& v) { return v.base && v.C % 4 == 0 && v.ldc % 4 == 0 && v.coff % 4 == 0; }
+
+int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s) {
+    if (!view_ok4(in) || !view_ok4(out) || out.H != 2 * in.H || out.W != 2 * in.W || out.C != in.C) {
+        set_error("upsample2x: bad views"); return RTOD_E_ARG;
+    }
+    const int64_t total = (int64_t)B * out.H * out.W * (in.C / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B);
+    return hip_fail(hipGetLastError(), "upsample2x launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone shortcut (src/darknet.py:263-268) for cfgs where the add cannot ride a conv epilogue
+__global__ void add_kernel(View a, View b, View out, int B) {
+    const int C4 = a.C / 4;
+    const int64_t total = (int64_t)B * a.H * a.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        const int64_t p = t / C4;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a.base + a.coff + c + p * a.ldc);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(b.base + b.coff + c + p * b.ldc);
+        *reinterpret_cast<f32x4*>(out.base + out.coff + c + p * out.ldc) = x + y;
+    }
+}
+
+int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s) {
+    if (!view_ok4(a) || !view_ok4(b) || !view_ok4(out) || a.C != b.C || a.C != out.C || a.H != b.H || a.W != b.W) {
+        set_error("add: bad views"); return RTOD_E_ARG;
+    }
+    const int64_t total = (int64_t)B * a.H * a.W * (a.C / 4);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, a, b, out, B);
+    return hip_fail(hipGetLastError(), "add launch");
+}
+
+// channel-slice copy (fallback when a route concat cannot be zero-copy)
+__global__ void copy_kernel(View a, View out, int B) {
+    const int C4 = a.C / 4;
+    const int64_t total = (int64_t)B * a.H * a.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        const int64_t p = t / C4;
+        *reinterpret_cast<f32x4*>(out.base + out.coff + c + p * out.ldc) =
+            *reinterpret_cast<const f32x4*>(a.base + a.coff + c + p * a.ldc);
+    }
+}
+
+int launch_copy(const View& a, const View& out, int B, hipStream_t s) {
+    if (!view_ok4(a) || !view_ok4(out) || a.C != out.C || a.H != out.H || a.W != out.W) {
+        set_error("copy: bad views"); return RTOD_E_ARG;
+    }
+    const int64_t total = (int64_t)B * a.H * a.W * (a.C / 4);
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, a, out, B);
+    return hip_fail(hipGetLastError(), "copy launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// max-pool: size/stride floor mode (nn.MaxPool2d, src/darknet.py:547-555); stride 1 = MaxPoolStride1
+// (src/darknet.py:17-46): replicate-pad right/bottom by size-1 then size/1 pool == clamp the window.
+__global__ void maxpool_kernel(View in, View out, int B, int size, int stride) {
+    const int C4 = in.C / 4;
+    const int64_t total = (int64_t)B * out.H * out.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        int64_t p = t / C4;
+        const int ox = (int)(p % out.W); p /= out.W;
+        const int oy = (int)(p % out.H);
+        const int b = (int)(p / out.H);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dy = 0; dy < size; ++dy) {
+            int iy = oy * stride + dy; if (iy > in.H - 1) iy = in.H - 1;
+            for (int dx = 0; dx < size; ++dx) {
+                int ix = ox * stride + dx; if (ix > in.W - 1) ix = in.W - 1;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in.base + in.coff + c + (((int64_t)b * in.H + iy) * in.W + ix) * in.ldc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(out.base + out.coff + c + (((int64_t)b * out.H + oy) * out.W + ox) * out.ldc) = m;
+    }
+}
+
+int launch_maxpool(const View& in, const View& out, int B, int size, int stride, hipStream_t s) {
+    if (!view_ok4(in) || !view_ok4(out) || in.C != out.C || size < 1 || stride < 1) { set_error("maxpool: bad views"); return RTOD_E_ARG; }
+    const int64_t total = (int64_t)B * out.H * out.W * (in.C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B, size, stride);
+    return hip_fail(hipGetLastError(), "maxpool launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC view -> dense NCHW (test/debug read-back of a layer output)
+__global__ void view_to_nchw_kernel(View in, int B, float* __restrict__ out) {
+    const int64_t total = (int64_t)B * in.C * in.H * in.W;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = t;
+        const int x = (int)(p % in.W); p /= in.W;
+        const int y = (int)(p % in.H); p /= in.H;
+        const int c = (int)(p % in.C);
+        const int b = (int)(p / in.C);
+        out[t] = in.base[(((int64_t)b * in.H + y) * in.W + x) * in.ldc + in.coff + c];
+    }
+}
+
+int launch_view_to_nchw(const View& in, int B, float* out, hipStream_t s) {
+    if (!in.base || !out) { set_error("view_to_nchw: null"); return RTOD_E_ARG; }
+    const int64_t total = (int64_t)B * in.C * in.H * in.W;
+    hipLaunchKernelGGL(view_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, B, out);
+    return hip_fail(hipGetLastError(), "view_to_nchw launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone head decode = predict_transform (src/util.py:175-239) over a strided raw tensor.
+// out row r = (gy*G + gx)*A + a, attribute c  <->  raw channel a*attrs + c at cell (gy, gx).
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ void decode_kernel(const float* __restrict__ raw, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                              int B, DecodeArgs d, float* __restrict__ out) {
+    const int AC = d.n_anchors * d.attrs;
+    const int64_t per_img = (int64_t)d.G * d.G * AC;
+    const int64_t total = (int64_t)B * per_img;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / per_img;
+        const int64_t r = t - b * per_img;
+        const int cell = (int)(r / AC);
+        const int n = (int)(r - (int64_t)cell * AC);
+        const int gy = cell / d.G, gx = cell - gy * d.G;
+        const int a = n / d.attrs, c = n - a * d.attrs;
+        float v = raw[b * sb + (int64_t)n * sc + (int64_t)gy * sy + (int64_t)gx * sx];
+        if (c >= 4) v = sigm(v);
+        else if (c < 2) { v = sigm(v); if (!d.train) v = (v + (float)(c == 0 ? gx : gy)) * d.stride; }
+        else if (!d.train) v = (expf(v) * (c == 2 ? d.aw[a] : d.ah[a])) * d.stride;
+        out[b * d.img_stride + d.head_off + r] = v;
+    }
+}
+
+int launch_decode(const float* raw, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B,
+                  const DecodeArgs& d, float* out, hipStream_t s) {
+    if (!raw || !out || d.G <= 0 || d.attrs < 5 || d.n_anchors < 1 || d.n_anchors > 4) { set_error("decode: bad args"); return RTOD_E_ARG; }
+    const int64_t total = (int64_t)B * d.G * d.G * d.n_anchors * d.attrs;
+    hipLaunchKernelGGL(decode_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, raw, sb, sc, sy, sx, B, d, out);
+    return hip_fail(hipGetLastError(), "decode launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// confidence_mask (src/util.py:106-117): out = pred * float(pred[...,4] > conf)
+__global__ void confidence_mask_kernel(const float* __restrict__ pred, int64_t rows, int attrs, float conf, float* __restrict__ out) {
+    const int64_t total = rows * attrs;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / attrs;
+        const float m = pred[r * attrs + 4] > conf ? 1.0f : 0.0f;
+        out[t] = pred[t] * m;
+    }
+}
+
+int launch_confidence_mask(const float* pred, int64_t rows, int attrs, float conf, float* out, hipStream_t s) {
+    if (!pred || !out || attrs < 5) { set_error("confidence_mask: bad args"); return RTOD_E_ARG; }
+    hipLaunchKernelGGL(confidence_mask_kernel, dim3(grid_for(rows * attrs, 256)), dim3(256), 0, s, pred, rows, attrs, conf, out);
+    return hip_fail(hipGetLastError(), "confidence_mask launch");
+}
+
+}  // namespace rtod

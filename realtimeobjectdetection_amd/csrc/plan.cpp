@@ -1,0 +1,653 @@
+// Plan construction + execution.  Behavioural sources in the reference (file:line into
+// /root/reference): cfg grammar src/darknet.py:428-447; channel bookkeeping and module semantics
+// src/darknet.py:449-603; forward interpreter src/darknet.py:199-303; weight stream order
+// src/darknet.py:316-410.
+#include "plan.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace rtod {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const std::string& last_error_string() { return g_err; }
+
+int hip_fail(hipError_t e, const char* what) {
+    if (e == hipSuccess) return RTOD_OK;
+    set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return RTOD_E_HIP;
+}
+
+const char* layer_type_name(int t) {
+    static const char* n[] = {"convolutional", "shortcut", "route", "upsample", "maxpool", "yolo"};
+    return (t >= 0 && t < 6) ? n[t] : "?";
+}
+
+Plan::~Plan() {
+    for (auto e : events) (void)hipEventDestroy(e);
+    if (d_arena) (void)hipFree(d_arena);
+    if (d_weights) (void)hipFree(d_weights);
+}
+
+// ------------------------------------------------------------------------------------- cfg
+static std::string rstrip(const std::string& s) {
+    size_t e = s.size();
+    while (e > 0 && isspace((unsigned char)s[e - 1])) --e;
+    return s.substr(0, e);
+}
+static std::string lstrip(const std::string& s) {
+    size_t b = 0;
+    while (b < s.size() && isspace((unsigned char)s[b])) ++b;
+    return s.substr(b);
+}
+
+static bool to_int(const std::string& s, int& out) {   // Python int(): optional surrounding blanks
+    const std::string t = rstrip(lstrip(s));
+    if (t.empty()) return false;
+    char* end = nullptr;
+    long v = strtol(t.c_str(), &end, 10);
+    if (*end) return false;
+    out = (int)v;
+    return true;
+}
+
+static std::vector<std::string> split(const std::string& s, char d) {
+    std::vector<std::string> out;
+    std::string cur;
+    for (char c : s) {
+        if (c == d) { out.push_back(cur); cur.clear(); } else cur.push_back(c);
+    }
+    out.push_back(cur);
+    return out;
+}
+
+struct Block { std::string type; std::map<std::string, std::string> kv; };
+
+static int parse_blocks(const std::string& text, std::vector<Block>& blocks) {
+    Block cur;
+    bool have = false;
+    for (const std::string& raw : split(text, '\n')) {
+        if (raw.empty()) continue;
+        if (raw[0] == '#') continue;                 // tested before stripping (darknet.py:432)
+        const std::string line = rstrip(lstrip(raw));
+        if (line.empty()) continue;
+        if (line[0] == '[') {
+            if (have) blocks.push_back(cur);
+            cur = Block();
+            have = true;
+            cur.type = rstrip(line.substr(1, line.size() >= 2 ? line.size() - 2 : 0));
+        } else {
+            const auto parts = split(line, '=');
+            if (parts.size() != 2 || !have) { set_error("cfg: malformed line '%s'", line.c_str()); return RTOD_E_CFG; }
+            cur.kv[rstrip(parts[0])] = lstrip(parts[1]);
+        }
+    }
+    if (have) blocks.push_back(cur);
+    if (blocks.empty() || blocks[0].type != "net") { set_error("cfg: first block must be [net]"); return RTOD_E_CFG; }
+    return RTOD_OK;
+}
+
+#define CFG_INT(blk, key, var)                                                                  \
+    do {                                                                                        \
+        auto _it = (blk).kv.find(key);                                                          \
+        if (_it == (blk).kv.end() || !to_int(_it->second, var)) {                               \
+            set_error("cfg: layer %d [%s]: missing/invalid '%s'", i, (blk).type.c_str(), key);  \
+            return RTOD_E_CFG;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+int Plan::parse(const std::string& text) {
+    std::vector<Block> blocks;
+    int rc = parse_blocks(text, blocks);
+    if (rc) return rc;
+    net_info = blocks[0].kv;
+    layers.clear();
+    for (size_t bi = 1; bi < blocks.size(); ++bi) {
+        const Block& b = blocks[bi];
+        const int i = (int)bi - 1;
+        Layer L;
+        L.index = i;
+        if (b.type == "convolutional") {
+            L.type = LT_CONV;
+            int bn = 0;
+            auto it = b.kv.find("batch_normalize");
+            L.bn = (it != b.kv.end() && to_int(it->second, bn) && bn != 0);
+            int padflag = 0;
+            CFG_INT(b, "filters", L.cout);
+            CFG_INT(b, "size", L.size);
+            CFG_INT(b, "stride", L.stride);
+            CFG_INT(b, "pad", padflag);
+            L.pad = padflag ? (L.size - 1) / 2 : 0;
+            auto act = b.kv.find("activation");
+            if (act == b.kv.end()) { set_error("cfg: layer %d: missing activation", i); return RTOD_E_CFG; }
+            L.leaky = act->second == "leaky";
+            if (L.cout < 1 || L.size < 1 || L.stride < 1) { set_error("cfg: layer %d: bad conv geometry", i); return RTOD_E_CFG; }
+        } else if (b.type == "upsample") {
+            L.type = LT_UPSAMPLE;
+            int st = 0;
+            CFG_INT(b, "stride", st);   // parsed but ignored: scale_factor=2 is hard-coded (darknet.py:589-592)
+            L.stride = 2;
+        } else if (b.type == "maxpool") {
+            L.type = LT_MAXPOOL;
+            CFG_INT(b, "size", L.size);
+            CFG_INT(b, "stride", L.stride);
+        } else if (b.type == "shortcut") {
+            L.type = LT_SHORTCUT;
+            int from = 0;
+            CFG_INT(b, "from", from);
+            L.srcs = {i - 1, i + from};
+        } else if (b.type == "route") {
+            L.type = LT_ROUTE;
+            auto it = b.kv.find("layers");
+            if (it == b.kv.end()) { set_error("cfg: layer %d: route without layers", i); return RTOD_E_CFG; }
+            for (const std::string& tok : split(it->second, ',')) {
+                int v = 0;
+                if (!to_int(tok, v)) { set_error("cfg: layer %d: bad route entry '%s'", i, tok.c_str()); return RTOD_E_CFG; }
+                L.srcs.push_back(v > 0 ? v : i + v);           // positive = absolute (darknet.py:274-275)
+            }
+            if (L.srcs.empty() || L.srcs.size() > 2) {         // the reference handles one or two sources only
+                set_error("cfg: layer %d: route with %zu sources unsupported", i, L.srcs.size()); return RTOD_E_CFG;
+            }
+        } else if (b.type == "yolo") {
+            L.type = LT_YOLO;
+            auto m = b.kv.find("mask"), a = b.kv.find("anchors");
+            if (m == b.kv.end() || a == b.kv.end()) { set_error("cfg: layer %d: yolo without mask/anchors", i); return RTOD_E_CFG; }
+            std::vector<int> av;
+            for (const std::string& tok : split(a->second, ',')) { int v; if (!to_int(tok, v)) { set_error("cfg: bad anchor"); return RTOD_E_CFG; } av.push_back(v); }
+            for (const std::string& tok : split(m->second, ',')) {
+                int v;
+                if (!to_int(tok, v) || v < 0 || 2 * v + 1 >= (int)av.size()) { set_error("cfg: layer %d: bad mask", i); return RTOD_E_CFG; }
+                L.anchors.push_back({av[2 * v], av[2 * v + 1]});
+            }
+            CFG_INT(b, "classes", L.classes);
+            if (L.anchors.empty() || L.anchors.size() > 4) { set_error("cfg: layer %d: 1..4 anchors per head supported", i); return RTOD_E_CFG; }
+        } else {
+            set_error("Unknown block error: A unknown block is provided: [%s]", b.type.c_str());   // darknet.py:524-526
+            return RTOD_E_CFG;
+        }
+        layers.push_back(L);
+    }
+    if (layers.empty()) { set_error("cfg: no layers"); return RTOD_E_CFG; }
+    return RTOD_OK;
+}
+
+int Plan::resolve_shapes() {
+    int pc = 3, ph = height, pw = width;
+    int row_off = 0;
+    int64_t woff = 0;
+    conv_flops = 0;
+    attrs = 0;
+    bool prev_is_decoded = false;
+    for (auto& L : layers) {
+        const int i = L.index;
+        auto src_ok = [&](int s) { return s >= 0 && s < i; };
+        if ((L.type == LT_CONV || L.type == LT_UPSAMPLE || L.type == LT_MAXPOOL || L.type == LT_YOLO) && prev_is_decoded) {
+            set_error("cfg: layer %d consumes a decoded yolo tensor (unsupported)", i); return RTOD_E_CFG;
+        }
+        L.cin = pc; L.hin = ph; L.win = pw;
+        switch (L.type) {
+            case LT_CONV:
+                L.hout = (ph + 2 * L.pad - L.size) / L.stride + 1;
+                L.wout = (pw + 2 * L.pad - L.size) / L.stride + 1;
+                if (L.hout < 1 || L.wout < 1) { set_error("cfg: layer %d: empty conv output", i); return RTOD_E_CFG; }
+                L.w_off = woff;
+                woff += (L.bn ? 4 : 1) * (int64_t)L.cout + (int64_t)L.cout * L.cin * L.size * L.size;
+                conv_flops += 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
+                break;
+            case LT_UPSAMPLE: L.cout = pc; L.hout = 2 * ph; L.wout = 2 * pw; break;
+            case LT_MAXPOOL:
+                L.cout = pc;
+                if (L.stride != 1) { L.hout = (ph - L.size) / L.stride + 1; L.wout = (pw - L.size) / L.stride + 1; }
+                else { L.hout = ph; L.wout = pw; }
+                if (L.hout < 1 || L.wout < 1) { set_error("cfg: layer %d: empty pool output", i); return RTOD_E_CFG; }
+                break;
+            case LT_SHORTCUT: {
+                if (i < 1 || !src_ok(L.srcs[1])) { set_error("cfg: layer %d: shortcut source out of range", i); return RTOD_E_CFG; }
+                const Layer& a = layers[L.srcs[0]]; const Layer& b = layers[L.srcs[1]];
+                if (a.cout != b.cout || a.hout != b.hout || a.wout != b.wout) { set_error("cfg: layer %d: shortcut shape mismatch", i); return RTOD_E_CFG; }
+                L.cout = a.cout; L.hout = a.hout; L.wout = a.wout;
+                break;
+            }
+            case LT_ROUTE: {
+                int c = 0;
+                for (int s : L.srcs) {
+                    if (!src_ok(s)) { set_error("cfg: layer %d: route source %d out of range", i, s); return RTOD_E_CFG; }
+                    if (layers[s].hout != layers[L.srcs[0]].hout || layers[s].wout != layers[L.srcs[0]].wout) { set_error("cfg: layer %d: route spatial mismatch", i); return RTOD_E_CFG; }
+                    c += layers[s].cout;
+                }
+                L.cout = c; L.cin = c; L.hout = layers[L.srcs[0]].hout; L.wout = layers[L.srcs[0]].wout;
+                break;
+            }
+            case LT_YOLO: {
+                if (i < 1) { set_error("cfg: yolo as first layer"); return RTOD_E_CFG; }
+                const int A = (int)L.anchors.size();
+                if (ph != pw) { set_error("cfg: layer %d: non-square head %dx%d unsupported (reference assumes square)", i, ph, pw); return RTOD_E_CFG; }
+                if (pc != A * (5 + L.classes)) { set_error("cfg: layer %d: head has %d channels, expected %d", i, pc, A * (5 + L.classes)); return RTOD_E_CFG; }
+                if (height % ph) { /* stride = inp_dim // G, G' = inp_dim // stride (util.py:194-195) must equal G */ }
+                if (height / (height / ph) != ph) { set_error("cfg: layer %d: grid %d does not divide input %d", i, ph, height); return RTOD_E_CFG; }
+                if (attrs && attrs != 5 + L.classes) { set_error("cfg: heads with different class counts"); return RTOD_E_CFG; }
+                attrs = 5 + L.classes;
+                L.cout = pc; L.hout = ph; L.wout = pw;
+                L.row_offset = row_off; L.rows = ph * pw * A;
+                row_off += L.rows;
+                break;
+            }
+        }
+        if (L.type == LT_YOLO) {
+            prev_is_decoded = true;       // x = decoded tensor; outputs[i] = outputs[i-1] (darknet.py:247)
+            pc = layers[i - 1].cout; ph = layers[i - 1].hout; pw = layers[i - 1].wout;
+        } else {
+            prev_is_decoded = false;
+            pc = L.cout; ph = L.hout; pw = L.wout;
+        }
+        if (L.type == LT_ROUTE || L.type == LT_SHORTCUT) prev_is_decoded = false;
+    }
+    total_rows = row_off;
+    n_weight_floats = woff;
+    if (total_rows == 0) { set_error("cfg: no yolo layer (the reference would return [])"); return RTOD_E_CFG; }
+    return RTOD_OK;
+}
+
+// ------------------------------------------------------------------------------------- planning
+static int resolve_alias(const std::vector<Layer>& layers, int i) {
+    while (layers[i].alias_of >= 0) i = layers[i].alias_of;
+    return i;
+}
+
+int Plan::plan_buffers() {
+    const int n = (int)layers.size();
+    // consumers of every layer's output
+    std::vector<std::vector<int>> cons(n);
+    for (const auto& L : layers) {
+        const int i = L.index;
+        switch (L.type) {
+            case LT_CONV: case LT_UPSAMPLE: case LT_MAXPOOL: case LT_YOLO: if (i > 0) cons[i - 1].push_back(i); break;
+            case LT_SHORTCUT: case LT_ROUTE: for (int s : L.srcs) cons[s].push_back(i); break;
+        }
+    }
+    // aliases
+    for (auto& L : layers) {
+        if (L.type == LT_ROUTE && L.srcs.size() == 1) L.alias_of = L.srcs[0];
+        if (L.type == LT_YOLO) L.alias_of = L.index - 1;
+    }
+    // fusions: conv -> shortcut, conv -> yolo
+    for (auto& L : layers) {
+        const int i = L.index;
+        if (i == 0) continue;
+        Layer& P = layers[i - 1];
+        if (P.type != LT_CONV || P.fused_into >= 0 || cons[i - 1].size() != 1) continue;
+        if (L.type == LT_SHORTCUT && L.srcs[1] != i - 1) { P.fused_into = i; L.fused_away = true; }
+        else if (L.type == LT_YOLO && cons[i].empty()) { P.fused_into = i; L.fused_away = true; }
+    }
+    // materialised producers: every non-alias layer except convs fused into the next layer and
+    // fused yolo layers (their "output" is the final tensor)
+    auto materialised = [&](const Layer& L) {
+        if (L.alias_of >= 0) return false;
+        if (L.type == LT_CONV && L.fused_into >= 0) return false;
+        if (L.type == LT_ROUTE) return true;      // two-source concat buffer
+        return true;
+    };
+    // zero-copy concat placement
+    bufs.clear();
+    std::vector<int> placed_buf(n, -1), placed_off(n, 0);
+    std::vector<std::vector<std::pair<int, int>>> route_copy(n);   // (src layer, coff) needing a copy
+    for (auto& L : layers) {
+        if (L.type != LT_ROUTE || L.srcs.size() < 2) continue;
+        Buffer b; b.C = L.cout; b.H = L.hout; b.W = L.wout;
+        const int bid = (int)bufs.size();
+        bufs.push_back(b);
+        L.buf = bid; L.coff = 0;
+        int off = 0;
+        for (int s : L.srcs) {
+            const int p = resolve_alias(layers, s);
+            const Layer& PL = layers[p];
+            const bool can = materialised(PL) && PL.type != LT_ROUTE && placed_buf[p] < 0 && off % 4 == 0 && PL.cout % 4 == 0 &&
+                             std::count(L.srcs.begin(), L.srcs.end(), s) == 1;
+            if (can) { placed_buf[p] = bid; placed_off[p] = off; }
+            else route_copy[L.index].push_back({s, off});
+            off += layers[s].cout;
+        }
+    }
+    // remaining materialised layers get their own buffer
+    for (auto& L : layers) {
+        if (!materialised(L) || L.buf >= 0) continue;
+        if (L.type == LT_YOLO) continue;
+        if (placed_buf[L.index] >= 0) { L.buf = placed_buf[L.index]; L.coff = placed_off[L.index]; continue; }
+        Buffer b; b.C = L.cout; b.H = L.hout; b.W = L.wout;
+        if (b.C % 4) { set_error("layer %d: %d channels not a multiple of 4 (unsupported for an intermediate tensor)", L.index, b.C); return RTOD_E_CFG; }
+        L.buf = (int)bufs.size(); L.coff = 0;
+        bufs.push_back(b);
+    }
+    // network input, packed NHWC with 4 channels
+    {
+        Buffer b; b.C = 4; b.H = height; b.W = width;
+        input_buf = (int)bufs.size();
+        bufs.push_back(b);
+    }
+    // launch list
+    launches.clear();
+    convs.clear();
+    { Launch l; l.kind = LK_PACK; l.layer = 0; launches.push_back(l); }
+    if (layers[0].type != LT_CONV) { set_error("cfg: first layer must be convolutional"); return RTOD_E_CFG; }
+    for (auto& L : layers) {
+        const int i = L.index;
+        Launch l; l.layer = i;
+        switch (L.type) {
+            case LT_CONV: {
+                l.kind = LK_CONV; l.in_layer = i - 1; l.out_layer = i;
+                if (L.fused_into >= 0) {
+                    const Layer& F = layers[L.fused_into];
+                    if (F.type == LT_SHORTCUT) { l.out_layer = F.index; l.in2_layer = F.srcs[1]; }
+                    else {
+                        l.out_layer = -2;
+                        DecodeArgs d; d.enabled = 1; d.G = F.hout; d.attrs = 5 + F.classes; d.n_anchors = (int)F.anchors.size();
+                        const int stride = height / F.hout;
+                        d.stride = (float)stride;
+                        for (size_t a = 0; a < F.anchors.size(); ++a) {
+                            d.aw[a] = (float)((double)F.anchors[a].first / (double)stride);     // Python float divide -> FloatTensor (util.py:213-216)
+                            d.ah[a] = (float)((double)F.anchors[a].second / (double)stride);
+                        }
+                        d.img_stride = (int64_t)total_rows * attrs; d.head_off = (int64_t)F.row_offset * attrs;
+                        l.dec = d;
+                    }
+                }
+                PackedConv pc; pc.layer = i; pc.cin_p = (i == 0) ? 4 : L.cin;
+                if (pc.cin_p % 4) { set_error("layer %d: %d input channels not a multiple of 4", i, pc.cin_p); return RTOD_E_CFG; }
+                pc.K = L.size * L.size * pc.cin_p; pc.Kpad = (pc.K + 31) / 32 * 32; pc.Npad = (L.cout + 127) / 128 * 128;
+                l.conv_slot = (int)convs.size();
+                convs.push_back(pc);
+                launches.push_back(l);
+                break;
+            }
+            case LT_UPSAMPLE: l.kind = LK_UPSAMPLE; l.in_layer = i - 1; l.out_layer = i; launches.push_back(l); break;
+            case LT_MAXPOOL: l.kind = LK_MAXPOOL; l.in_layer = i - 1; l.out_layer = i; launches.push_back(l); break;
+            case LT_SHORTCUT:
+                if (!L.fused_away) { l.kind = LK_ADD; l.in_layer = L.srcs[0]; l.in2_layer = L.srcs[1]; l.out_layer = i; launches.push_back(l); }
+                break;
+            case LT_ROUTE:
+                for (auto& sc : route_copy[i]) { Launch c; c.kind = LK_COPY; c.layer = i; c.in_layer = sc.first; c.out_buf = L.buf; c.out_coff = sc.second; c.out_layer = i; launches.push_back(c); }
+                break;
+            case LT_YOLO:
+                if (!L.fused_away) {
+                    l.kind = LK_DECODE; l.in_layer = i - 1; l.out_layer = -2;
+                    DecodeArgs d; d.enabled = 1; d.G = L.hout; d.attrs = 5 + L.classes; d.n_anchors = (int)L.anchors.size();
+                    const int stride = height / L.hout;
+                    d.stride = (float)stride;
+                    for (size_t a = 0; a < L.anchors.size(); ++a) {
+                        d.aw[a] = (float)((double)L.anchors[a].first / (double)stride);
+                        d.ah[a] = (float)((double)L.anchors[a].second / (double)stride);
+                    }
+                    d.img_stride = (int64_t)total_rows * attrs; d.head_off = (int64_t)L.row_offset * attrs;
+                    l.dec = d;
+                    launches.push_back(l);
+                }
+                break;
+        }
+    }
+    // liveness per buffer over launch time (= layer index of the launch)
+    const int NB = (int)bufs.size();
+    for (auto& b : bufs) { b.first = 1 << 30; b.last = -1; }
+    auto touch = [&](int buf, int t) { if (buf < 0) return; bufs[buf].first = std::min(bufs[buf].first, t); bufs[buf].last = std::max(bufs[buf].last, t); };
+    auto buf_of_layer = [&](int layer) { if (layer < 0) return input_buf; return layers[resolve_alias(layers, layer)].buf; };
+    for (const auto& l : launches) {
+        const int t = l.layer;
+        if (l.kind == LK_PACK) { touch(input_buf, 0); continue; }
+        touch(buf_of_layer(l.in_layer), t);
+        if (l.in2_layer >= 0) touch(buf_of_layer(l.in2_layer), t);
+        if (l.kind == LK_COPY) touch(l.out_buf, t);
+        else if (l.out_layer >= 0) touch(buf_of_layer(l.out_layer), t);
+    }
+    // a concat buffer is live from its first producer to its last consumer: touches above cover both
+    for (int b = 0; b < NB; ++b) {
+        if (bufs[b].last < 0) { bufs[b].first = bufs[b].last = 0; }      // never used (dead layer): still give it space
+        bufs[b].floats_per_frame = (int64_t)bufs[b].C * bufs[b].H * bufs[b].W;
+    }
+    assign_arena();
+    // packed weight arena layout
+    packed_floats = 0;
+    for (auto& pc : convs) {
+        pc.w_off = packed_floats; packed_floats += (int64_t)pc.Npad * pc.Kpad;
+        pc.b_off = packed_floats; packed_floats += pc.Npad;
+        packed_floats = (packed_floats + 63) / 64 * 64;
+    }
+    return RTOD_OK;
+}
+
+void Plan::assign_arena() {
+    const int NB = (int)bufs.size();
+    // greedy arena assignment (first fit by offset among lifetime-overlapping buffers)
+    std::vector<int> order(NB);
+    for (int i = 0; i < NB; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return bufs[a].first != bufs[b].first ? bufs[a].first < bufs[b].first : a < b; });
+    std::vector<int> done;
+    arena_floats = 0;
+    for (int id : order) {
+        Buffer& B = bufs[id];
+        const int64_t size = (B.floats_per_frame * max_batch + 63) / 64 * 64;   // 256-B granules
+        std::vector<std::pair<int64_t, int64_t>> busy;
+        for (int o : done) {
+            const Buffer& O = bufs[o];
+            if (!keep_all && (O.last < B.first || O.first > B.last)) continue;
+            busy.push_back({O.offset, O.offset + (O.floats_per_frame * max_batch + 63) / 64 * 64});
+        }
+        std::sort(busy.begin(), busy.end());
+        int64_t off = 0;
+        for (auto& iv : busy) { if (off + size <= iv.first) break; off = std::max(off, iv.second); }
+        B.offset = off;
+        arena_floats = std::max(arena_floats, off + size);
+        done.push_back(id);
+    }
+}
+
+View Plan::view_of(int layer) const {
+    View v;
+    if (layer < 0) {
+        const Buffer& b = bufs[input_buf];
+        v.base = d_arena ? d_arena + b.offset : nullptr; v.ldc = 4; v.coff = 0; v.C = 4; v.H = height; v.W = width;
+        return v;
+    }
+    const Layer& L = layers[resolve_alias(layers, layer)];
+    if (L.buf < 0) return v;
+    const Buffer& b = bufs[L.buf];
+    v.base = d_arena ? d_arena + b.offset : nullptr;
+    v.ldc = b.C; v.coff = L.coff; v.C = L.cout; v.H = L.hout; v.W = L.wout;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------- weights
+int Plan::load_weights(const float* w, size_t n) {
+    if (!w) { set_error("load_weights: null pointer"); return RTOD_E_ARG; }
+    if ((int64_t)n < n_weight_floats) {
+        set_error("load_weights: stream has %zu floats, network needs %lld", n, (long long)n_weight_floats);
+        return RTOD_E_SIZE;
+    }
+    RTOD_HIP(hipSetDevice(device));
+    std::vector<float> packed((size_t)packed_floats, 0.0f);
+    for (const auto& pc : convs) {
+        const Layer& L = layers[pc.layer];
+        const float* p = w + L.w_off;
+        const int C = L.cout, cin = L.cin, k = L.size;
+        std::vector<double> scale(C, 1.0);
+        float* bias = packed.data() + pc.b_off;
+        if (L.bn) {
+            const float *beta = p, *gamma = p + C, *mean = p + 2 * C, *var = p + 3 * C;
+            for (int o = 0; o < C; ++o) {
+                // eval BatchNorm (x - mean) / sqrt(var + 1e-5) * gamma + beta folded into the conv
+                const double s = (double)gamma[o] / std::sqrt((double)var[o] + 1e-5);
+                scale[o] = s;
+                bias[o] = (float)((double)beta[o] - (double)mean[o] * s);
+            }
+            p += 4 * C;
+        } else {
+            for (int o = 0; o < C; ++o) bias[o] = p[o];
+            p += C;
+        }
+        float* wp = packed.data() + pc.w_off;
+        for (int o = 0; o < C; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx) {
+                        const float v = p[(((int64_t)o * cin + c) * k + ky) * k + kx];          // OIHW
+                        wp[(int64_t)o * pc.Kpad + (ky * k + kx) * pc.cin_p + c] = (float)((double)v * scale[o]);
+                    }
+    }
+    if (!d_weights) RTOD_HIP(hipMalloc((void**)&d_weights, sizeof(float) * (size_t)packed_floats));
+    if (!d_arena) {
+        RTOD_HIP(hipMalloc((void**)&d_arena, sizeof(float) * (size_t)arena_floats));
+        RTOD_HIP(hipMemset(d_arena, 0, sizeof(float) * (size_t)arena_floats));
+    }
+    RTOD_HIP(hipMemcpy(d_weights, packed.data(), sizeof(float) * (size_t)packed_floats, hipMemcpyHostToDevice));
+    RTOD_HIP(hipDeviceSynchronize());
+    weights_loaded = true;
+    return RTOD_OK;
+}
+
+// ------------------------------------------------------------------------------------- forward
+int Plan::choose_variant(const Layer& L, int batch) const {
+    const char* force = getenv("RTOD_CONV_VARIANT");
+    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < CV_COUNT) return v; }
+    if (L.cout <= 32) return CV_128x32;
+    if (L.cout <= 64) return CV_128x64;
+    const int64_t M = (int64_t)batch * L.hout * L.wout;
+    const int64_t big = ((M + 127) / 128) * ((L.cout + 127) / 128);
+    return big >= 512 ? CV_128x128 : CV_64x64;     // keep >= 2 workgroups per CU in flight
+}
+
+int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms) {
+    if (!weights_loaded) { set_error("forward: load_weights has not been called"); return RTOD_E_STATE; }
+    if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
+    if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
+    RTOD_HIP(hipSetDevice(device));
+    const size_t nl = launches.size();
+    if (launch_ms && events.size() < 2 * nl) {
+        while (events.size() < 2 * nl) { hipEvent_t e; RTOD_HIP(hipEventCreate(&e)); events.push_back(e); }
+    }
+    for (size_t li = 0; li < nl; ++li) {
+        const Launch& l = launches[li];
+        if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li], s));
+        int rc = RTOD_OK;
+        switch (l.kind) {
+            case LK_PACK: {
+                View v = view_of(-1);
+                rc = launch_pack_input(x, batch, 3, height, width, v.base, 4, s);
+                break;
+            }
+            case LK_CONV: {
+                const Layer& L = layers[l.layer];
+                const PackedConv& pc = convs[l.conv_slot];
+                const View in = view_of(l.in_layer);
+                ConvArgs a;
+                a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
+                a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
+                a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
+                a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
+                a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
+                if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
+                if (l.out_layer == -2) { a.out = out; a.dec = l.dec; a.dec.train = train_decode; }
+                else {
+                    const View o = view_of(l.out_layer);
+                    if (!o.base || o.C != L.cout || o.H != L.hout || o.W != L.wout) { set_error("forward: layer %d output view mismatch", l.layer); return RTOD_E_STATE; }
+                    a.out = o.base; a.out_ldc = o.ldc; a.out_coff = o.coff;
+                }
+                if (l.in2_layer >= 0) {
+                    const View r = view_of(l.in2_layer);
+                    if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
+                    a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
+                }
+                rc = launch_conv(a, choose_variant(L, batch), s);
+                break;
+            }
+            case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;
+            case LK_MAXPOOL: rc = launch_maxpool(view_of(l.in_layer), view_of(l.out_layer), batch, layers[l.layer].size, layers[l.layer].stride, s); break;
+            case LK_ADD: rc = launch_add(view_of(l.in_layer), view_of(l.in2_layer), view_of(l.out_layer), batch, s); break;
+            case LK_COPY: {
+                const View in = view_of(l.in_layer);
+                View o; const Buffer& b = bufs[l.out_buf];
+                o.base = d_arena + b.offset; o.ldc = b.C; o.coff = l.out_coff; o.C = in.C; o.H = in.H; o.W = in.W;
+                rc = launch_copy(in, o, batch, s);
+                break;
+            }
+            case LK_DECODE: {
+                const View in = view_of(l.in_layer);
+                // NHWC strides of the raw head tensor
+                DecodeArgs d = l.dec; d.train = train_decode;
+                rc = launch_decode(in.base + in.coff, (int64_t)in.H * in.W * in.ldc, 1, (int64_t)in.W * in.ldc, in.ldc, batch, d, out, s);
+                break;
+            }
+        }
+        if (rc) return rc;
+        if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li + 1], s));
+    }
+    if (launch_ms) {
+        RTOD_HIP(hipEventSynchronize(events[2 * nl - 1]));
+        for (size_t li = 0; li < nl; ++li) RTOD_HIP(hipEventElapsedTime(&launch_ms[li], events[2 * li], events[2 * li + 1]));
+    }
+    return RTOD_OK;
+}
+
+void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
+    memset(o, 0, sizeof(*o));
+    const Launch& l = launches[idx];
+    o->layer = l.layer; o->kind = l.kind; o->variant = -1;
+    if (l.kind == LK_PACK) { o->bytes_per_frame = (int64_t)height * width * (3 + 4) * 4; return; }
+    const Layer& L = layers[l.layer];
+    o->ksize = L.size; o->stride = L.stride; o->cin = L.cin; o->cout = L.cout; o->hout = L.hout; o->wout = L.wout;
+    const int64_t in_b = (int64_t)L.hin * L.win * L.cin * 4, out_b = (int64_t)L.hout * L.wout * L.cout * 4;
+    switch (l.kind) {
+        case LK_CONV:
+            o->variant = choose_variant(L, batch);
+            o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
+            o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
+            o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);
+            o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
+            break;
+        case LK_ADD: o->bytes_per_frame = 3 * out_b; break;
+        default: o->bytes_per_frame = in_b + out_b; break;
+    }
+}
+
+std::string Plan::describe() const {
+    std::ostringstream os;
+    os << "{\"height\":" << height << ",\"width\":" << width << ",\"total_rows\":" << total_rows << ",\"attrs\":" << attrs
+       << ",\"n_weight_floats\":" << n_weight_floats << ",\"conv_flops\":" << conv_flops << ",\"arena_floats\":" << arena_floats
+       << ",\"n_launches\":" << launches.size() << ",\"layers\":[";
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const Layer& L = layers[i];
+        if (i) os << ",";
+        os << "{\"index\":" << L.index << ",\"type\":\"" << layer_type_name(L.type) << "\",\"cin\":" << L.cin << ",\"cout\":" << L.cout
+           << ",\"hin\":" << L.hin << ",\"win\":" << L.win << ",\"hout\":" << L.hout << ",\"wout\":" << L.wout << ",\"size\":" << L.size
+           << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"bn\":" << (L.bn ? "true" : "false") << ",\"leaky\":" << (L.leaky ? "true" : "false")
+           << ",\"srcs\":[";
+        for (size_t s = 0; s < L.srcs.size(); ++s) os << (s ? "," : "") << L.srcs[s];
+        os << "],\"anchors\":[";
+        for (size_t a = 0; a < L.anchors.size(); ++a) os << (a ? "," : "") << "[" << L.anchors[a].first << "," << L.anchors[a].second << "]";
+        os << "],\"classes\":" << L.classes << ",\"row_offset\":" << L.row_offset << ",\"rows\":" << L.rows << ",\"w_off\":" << L.w_off
+           << ",\"fused_into\":" << L.fused_into << ",\"fused_away\":" << (L.fused_away ? "true" : "false") << ",\"alias_of\":" << L.alias_of
+           << ",\"buf\":" << L.buf << ",\"coff\":" << L.coff << "}";
+    }
+    os << "],\"bufs\":[";
+    for (size_t i = 0; i < bufs.size(); ++i) {
+        const Buffer& b = bufs[i];
+        if (i) os << ",";
+        os << "{\"C\":" << b.C << ",\"H\":" << b.H << ",\"W\":" << b.W << ",\"first\":" << b.first << ",\"last\":" << b.last << ",\"offset\":" << b.offset
+           << ",\"floats_per_frame\":" << b.floats_per_frame << "}";
+    }
+    os << "]}";
+    return os.str();
+}
+
+}  // namespace rtod

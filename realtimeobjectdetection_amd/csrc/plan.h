@@ -1,0 +1,89 @@
+// Static execution plan of a Darknet cfg on one GPU: layer IR, NHWC buffer arena with liveness
+// reuse, zero-copy route concat, fused shortcut / head-decode epilogues, packed weights, launch list.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rtod_internal.h"
+
+namespace rtod {
+
+enum LayerType { LT_CONV = 0, LT_SHORTCUT, LT_ROUTE, LT_UPSAMPLE, LT_MAXPOOL, LT_YOLO };
+const char* layer_type_name(int t);
+
+struct Layer {
+    int index = 0;
+    int type = LT_CONV;
+    int cin = 0, cout = 0, hin = 0, win = 0, hout = 0, wout = 0;
+    int size = 0, stride = 1, pad = 0;
+    bool bn = false, leaky = false;
+    std::vector<int> srcs;                       // absolute layer indices (route / shortcut)
+    std::vector<std::pair<int, int>> anchors;    // yolo: masked (w,h) pairs
+    int classes = 0, row_offset = 0, rows = 0;
+    int64_t w_off = 0;                           // float offset of this conv's block in the .weights payload
+    // planning results
+    int fused_into = -1;      // conv: index of the shortcut/yolo layer whose output it writes
+    bool fused_away = false;  // shortcut / yolo executed inside the preceding conv's epilogue
+    int buf = -1, coff = 0;   // materialised output: arena buffer id + channel offset (-1: none/alias)
+    int alias_of = -1;        // single-source route / yolo: same view as that layer
+};
+
+struct Buffer {
+    int C = 0, H = 0, W = 0;      // C = ldc (full pixel width)
+    int first = 0, last = 0;      // launch-time interval (layer indices) in which it is live
+    int64_t floats_per_frame = 0;
+    int64_t offset = 0;           // floats from arena base, for max_batch frames
+};
+
+enum LaunchKind { LK_CONV = 0, LK_PACK = 1, LK_UPSAMPLE = 2, LK_ADD = 3, LK_MAXPOOL = 4, LK_DECODE = 5, LK_COPY = 6 };
+
+struct Launch {
+    int kind = LK_CONV;
+    int layer = 0;
+    int in_layer = -1;        // layer whose output view is read (-1: network input buffer)
+    int in2_layer = -1;       // residual / second operand
+    int out_layer = -1;       // layer whose view is written (-2: final [B,N,attrs] output)
+    int out_buf = -1, out_coff = 0;   // for LK_COPY into a concat slice
+    int conv_slot = -1;       // index into Plan::convs
+    DecodeArgs dec;
+};
+
+struct PackedConv {
+    int layer = 0;
+    int cin_p = 0, K = 0, Kpad = 0, Npad = 0;
+    int64_t w_off = 0, b_off = 0;     // float offsets into the device weight arena
+};
+
+struct Plan {
+    int height = 0, width = 0, max_batch = 0, device = 0;
+    std::map<std::string, std::string> net_info;
+    std::vector<Layer> layers;
+    std::vector<Buffer> bufs;
+    int input_buf = -1;
+    std::vector<Launch> launches;
+    std::vector<PackedConv> convs;
+    int total_rows = 0, attrs = 0;
+    int64_t n_weight_floats = 0, conv_flops = 0;
+    int64_t arena_floats = 0, packed_floats = 0;
+    float* d_arena = nullptr;
+    float* d_weights = nullptr;
+    bool weights_loaded = false;
+    int train_decode = 0;
+    bool keep_all = false;     // debug: no arena reuse, every layer output stays readable after forward
+    std::vector<hipEvent_t> events;
+
+    ~Plan();
+    int parse(const std::string& cfg_text);
+    int resolve_shapes();
+    int plan_buffers();
+    void assign_arena();
+    int load_weights(const float* w, size_t n);
+    int forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms);
+    View view_of(int layer) const;            // resolves aliases; base == nullptr if not materialised
+    int choose_variant(const Layer& L, int batch) const;
+    std::string describe() const;
+    void fill_launch_info(int idx, rtod_launch_info* o, int batch) const;
+};
+
+}  // namespace rtod

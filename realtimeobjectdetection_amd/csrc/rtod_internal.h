@@ -1,0 +1,80 @@
+// Internal declarations shared by the kernels, the plan and the C ABI (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/rtod.h"
+
+namespace rtod {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define RTOD_HIP(expr)                                              \
+    do {                                                            \
+        hipError_t _e = (expr);                                     \
+        if (_e != hipSuccess) return ::rtod::hip_fail(_e, #expr);   \
+    } while (0)
+
+// NHWC view of an activation: element (b,y,x,c) at base[((b*H + y)*W + x)*ldc + coff + c]
+struct View {
+    float* base = nullptr;
+    int64_t ldc = 0;   // floats between consecutive pixels (>= C: concat buffers are wider)
+    int coff = 0;      // first channel of this view inside the pixel
+    int C = 0, H = 0, W = 0;
+};
+
+// Fused YOLO head decode (reference: src/util.py:193-237) applied in a conv epilogue or by the
+// stand-alone kernel.
+struct DecodeArgs {
+    int enabled = 0;
+    int G = 0;               // grid size
+    int attrs = 0;           // 5 + classes
+    int n_anchors = 0;
+    int train = 0;           // TRAIN=True: sigmoids only
+    float stride = 0.f;      // inp_dim // G
+    float aw[4] = {0, 0, 0, 0};   // fp32(anchor_w / stride)
+    float ah[4] = {0, 0, 0, 0};
+    int64_t img_stride = 0;  // total_rows * attrs
+    int64_t head_off = 0;    // row_offset * attrs
+};
+
+struct ConvArgs {
+    const float* in = nullptr;  int64_t in_ldc = 0;  int in_coff = 0;
+    int B = 0, Hi = 0, Wi = 0, Cin = 0;        // Cin = stored channels of the input view
+    const float* w = nullptr;                   // packed [Npad][Kpad], k = (ky*kw+kx)*Cin + c
+    const float* bias = nullptr;                // [Npad]
+    int K = 0, Kpad = 0;
+    int kh = 1, kw = 1, stride = 1, pad = 0;
+    int Ho = 0, Wo = 0, Cout = 0;
+    float* out = nullptr;       int64_t out_ldc = 0; int out_coff = 0;
+    const float* res = nullptr; int64_t res_ldc = 0; int res_coff = 0;   // fused shortcut
+    int leaky = 0;
+    DecodeArgs dec;
+};
+
+enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, CV_COUNT };
+struct ConvVariantInfo { int bm, bn; const char* name; };
+const ConvVariantInfo& conv_variant_info(int v);
+int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
+
+int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
+int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
+int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s);
+int launch_maxpool(const View& in, const View& out, int B, int size, int stride, hipStream_t s);
+int launch_copy(const View& in, const View& out, int B, hipStream_t s);
+int launch_view_to_nchw(const View& in, int B, float* out_nchw, hipStream_t s);
+// strided decode: raw element (b, ch, y, x) at raw[b*sb + ch*sc + y*sy + x*sx]
+int launch_decode(const float* raw, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B,
+                  const DecodeArgs& d, float* out, hipStream_t s);
+int launch_confidence_mask(const float* pred, int64_t rows, int attrs, float conf, float* out, hipStream_t s);
+int launch_bbox_iou(const float* box1, const float* boxes, int k, int row_stride, float* iou, hipStream_t s);
+
+size_t nms_workspace_bytes(int batch, int n);
+int launch_write_results(const float* pred, int batch, int n, int num_class, float conf, float nms,
+                         float* out, int cap, int32_t* counts, void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace rtod

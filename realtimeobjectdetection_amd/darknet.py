@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's ``Darknet`` class, backed by librtod.so.
+
+Drop-in surface (reference: src/darknet.py:138-603, SURVEY.md §8 b): ``Darknet(cfg_file_path, CUDA)``,
+``.blocks`` / ``.net_info`` (mutable; callers set ``net_info["height"]``) / ``.module_list`` /
+``.header`` / ``.seen`` / ``.CUDA`` / ``.TRAIN``, ``get_blocks()``, ``get_module_list()``,
+``load_weights(path)``, ``load_state_dict`` with the reference's key names
+(``module_list.{i}.conv_{i}.weight`` ...), ``forward(x) -> [B,N,5+C]``, ``train_mode()``, and after
+the first forward ``.anchors`` / ``.num_classes``.
+
+Everything numeric happens in hand-written HIP kernels behind the C ABI (include/rtod.h).  The
+``nn.Module`` tree only *holds* the parameters in the reference's layout so ``state_dict`` /
+``.parameters()`` / ``.cuda()`` keep working; PyTorch executes none of the network.  There is no
+CPU fallback: a non-CUDA input or a missing librtod.so raises.
+
+BatchNorm runs with running statistics (``.eval()`` semantics) folded into the convolutions — the
+canonical mode of SURVEY.md F2.  The reference's callers never call ``.eval()``, so there BN uses
+batch statistics (frames of a batch influence each other); that mode is not implemented and
+``forward`` refuses to run while ``self.training`` is set unless ``bn_running_stats_in_train`` is
+enabled explicitly.
+"""
+import ctypes as C
+import json
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _ffi
+from .cfg import parse_cfg, build_ir
+
+
+class EmptyLayer(nn.Module):
+    """Placeholder for route / shortcut blocks (reference: src/darknet.py:49-54)."""
+
+
+class DetectionLayer(nn.Module):
+    """Holds the masked anchors of a yolo block (reference: src/darknet.py:57-97)."""
+
+    def __init__(self, anchors, CUDA=False):
+        super().__init__()
+        self.anchors = anchors
+        self.CUDA = CUDA
+
+
+class MaxPoolStride1(nn.Module):
+    """Marker for ``[maxpool] stride=1`` (reference: src/darknet.py:17-46); executed by librtod."""
+
+    def __init__(self, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.pad = kernel_size - 1
+
+
+def _blocks_to_cfg_text(blocks) -> str:
+    """Serialise parsed blocks back to cfg text for the native parser (route ``layers`` may have
+    been split into a list by create_modules, as in the reference, src/darknet.py:564)."""
+    out = []
+    for b in blocks:
+        out.append("[%s]" % b["type"])
+        for k, v in b.items():
+            if k == "type":
+                continue
+            if isinstance(v, (list, tuple)):
+                v = ",".join(str(a) for a in v)
+            out.append("%s=%s" % (k, v))
+        out.append("")
+    return "\n".join(out) + "\n"
+
+
+class Darknet(nn.Module):
+    def __init__(self, cfg_file_path, CUDA):
+        super().__init__()
+        self.blocks = self.parse_cfg(cfg_file_path)
+        self.net_info, self.module_list = self.create_modules(self.blocks)
+        self.header = torch.IntTensor([0, 0, 0, 0])
+        self.seen = 0
+        self.CUDA = CUDA
+        self.TRAIN = False
+        self.bn_running_stats_in_train = False
+        self.keep_all_layers = False      # debug: no activation-arena reuse (read_layer after forward)
+        self._cfg_text = _blocks_to_cfg_text(self.blocks)
+        self._plan = None
+        self._plan_key = None
+        self._weights_version = 0
+        self._plan_weights_version = -1
+        self._info = None
+
+    # ------------------------------------------------------------------ reference getters
+    def get_blocks(self) -> list:
+        return self.blocks
+
+    def get_module_list(self) -> nn.ModuleList:
+        return self.module_list
+
+    @staticmethod
+    def parse_cfg(cfg_file_path):
+        return parse_cfg(cfg_file_path)
+
+    @staticmethod
+    def create_modules(blocks):
+        """Same module tree / parameter names as the reference builds (src/darknet.py:449-603) so
+        state_dicts are interchangeable; shapes come from the shared IR."""
+        net_info = blocks[0]
+        ir = build_ir(blocks, int(net_info.get("height", 416)))
+        module_list = nn.ModuleList()
+        for L, blk in zip(ir.layers, blocks[1:]):
+            i = L.index
+            m = nn.Sequential()
+            if L.type == "convolutional":
+                m.add_module("conv_%d" % i, nn.Conv2d(L.cin, L.cout, L.size, L.stride, L.pad, bias=not L.bn))
+                if L.bn:
+                    m.add_module("batch_norm_%d" % i, nn.BatchNorm2d(L.cout))
+                if L.leaky:
+                    m.add_module("leaky_%d" % i, nn.LeakyReLU(0.1, inplace=True))
+            elif L.type == "upsample":
+                m.add_module("upsample_%d" % i, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+            elif L.type == "route":
+                if isinstance(blk["layers"], str):
+                    blk["layers"] = blk["layers"].split(",")        # the reference splits in place
+                m.add_module("route_%d" % i, EmptyLayer())
+            elif L.type == "shortcut":
+                m.add_module("shortcut_%d" % i, EmptyLayer())
+            elif L.type == "maxpool":
+                m.add_module("maxpool_%d" % i, nn.MaxPool2d(L.size, L.stride) if L.stride != 1 else MaxPoolStride1(L.size))
+            elif L.type == "yolo":
+                m.add_module("Detection_%d" % i, DetectionLayer([tuple(a) for a in L.anchors]))
+            module_list.append(m)
+        return net_info, module_list
+
+    # ------------------------------------------------------------------ weights
+    def configure_weights(self, weight_file_path):
+        with open(weight_file_path, "rb") as fp:
+            header = np.fromfile(fp, dtype=np.int32, count=5)
+            weights = np.fromfile(fp, dtype=np.float32)
+        self.header = torch.from_numpy(header)
+        self.seen = self.header[3]
+        return weights
+
+    def load_weights(self, weight_file_path: str):
+        """Darknet binary -> module tensors (reference: src/darknet.py:316-410)."""
+        w = self.configure_weights(weight_file_path)
+        self.load_weight_stream(w)
+
+    def load_weight_stream(self, w: np.ndarray):
+        ptr = 0
+        with torch.no_grad():
+            for m in self.module_list:
+                conv = bn = None
+                for name, sub in m.named_children():
+                    if name.startswith("conv_"):
+                        conv = sub
+                    elif name.startswith("batch_norm_"):
+                        bn = sub
+                if conv is None:
+                    continue
+                c = conv.out_channels
+                if bn is not None:
+                    for t in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                        t.copy_(torch.from_numpy(w[ptr:ptr + c]).view_as(t)); ptr += c
+                else:
+                    conv.bias.copy_(torch.from_numpy(w[ptr:ptr + c]).view_as(conv.bias)); ptr += c
+                n = conv.weight.numel()
+                conv.weight.copy_(torch.from_numpy(w[ptr:ptr + n]).view_as(conv.weight)); ptr += n
+        self._weights_version += 1
+        return ptr
+
+    def weight_stream(self) -> np.ndarray:
+        """Current parameters as a ``.weights`` float payload (host, float32)."""
+        parts = []
+        for m in self.module_list:
+            conv = bn = None
+            for name, sub in m.named_children():
+                if name.startswith("conv_"):
+                    conv = sub
+                elif name.startswith("batch_norm_"):
+                    bn = sub
+            if conv is None:
+                continue
+            if bn is not None:
+                parts += [bn.bias, bn.weight, bn.running_mean, bn.running_var]
+            else:
+                parts.append(conv.bias)
+            parts.append(conv.weight)
+        return np.concatenate([p.detach().float().cpu().numpy().reshape(-1) for p in parts]).astype(np.float32, copy=False)
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._weights_version += 1
+        return r
+
+    def invalidate_weights(self):
+        """Call after mutating parameters in place so the next forward re-packs them."""
+        self._weights_version += 1
+
+    # ------------------------------------------------------------------ plan
+    def _destroy_plan(self):
+        if self._plan is not None:
+            _ffi.lib().rtod_plan_destroy(self._plan)
+            self._plan = None
+            self._plan_key = None
+
+    def __del__(self):
+        try:
+            self._destroy_plan()
+        except Exception:
+            pass
+
+    def prepare(self, max_batch: int, device=None):
+        """Build the native plan for ``net_info['height']`` and ``max_batch`` frames and upload the
+        BN-folded, K-major packed weights.  Called lazily by ``forward``."""
+        lib = _ffi.lib()
+        if device is None:
+            device = torch.cuda.current_device()
+        device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        inp_dim = int(self.net_info["height"])
+        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers))
+        if self._plan is None or self._plan_key != key:
+            self._destroy_plan()
+            h = C.c_void_p()
+            txt = self._cfg_text.encode()
+            _ffi.check(lib.rtod_plan_create(txt, len(txt), inp_dim, inp_dim, int(max_batch), device.index, C.byref(h)))
+            self._plan, self._plan_key = h, key
+            if self.keep_all_layers:
+                _ffi.check(lib.rtod_plan_set_keep_all_layers(self._plan, 1))
+            self._plan_weights_version = -1
+            info = _ffi.PlanInfo()
+            _ffi.check(lib.rtod_plan_get_info(self._plan, C.byref(info)))
+            self._info = info
+        if self._plan_weights_version != self._weights_version:
+            w = np.ascontiguousarray(self.weight_stream())
+            with torch.cuda.device(device):
+                _ffi.check(lib.rtod_plan_load_weights(self._plan, w.ctypes.data_as(C.c_void_p), w.size))
+            self._plan_weights_version = self._weights_version
+        return self._info
+
+    def plan_description(self) -> dict:
+        lib = _ffi.lib()
+        need = C.c_size_t()
+        _ffi.check(lib.rtod_plan_describe(self._plan, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _ffi.check(lib.rtod_plan_describe(self._plan, buf, need.value, None))
+        return json.loads(buf.value.decode())
+
+    def launch_infos(self):
+        lib = _ffi.lib()
+        out = []
+        for i in range(self._info.n_launches):
+            li = _ffi.LaunchInfo()
+            _ffi.check(lib.rtod_plan_get_launch(self._plan, i, C.byref(li)))
+            out.append(li)
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError("Darknet.forward: input must be a CUDA (ROCm) tensor; this build has no CPU path")
+        if x.dtype != torch.float32 or x.dim() != 4 or x.size(1) != 3:
+            raise ValueError("Darknet.forward: expected float32 [B,3,H,W], got %s %s" % (x.dtype, tuple(x.shape)))
+        inp_dim = int(self.net_info["height"])
+        if x.size(2) != inp_dim or x.size(3) != inp_dim:
+            raise ValueError("Darknet.forward: input is %dx%d but net_info['height'] = %d (set it like detect.py:47 does)"
+                             % (x.size(2), x.size(3), inp_dim))
+        if self.training and not self.bn_running_stats_in_train:
+            raise NotImplementedError(
+                "Darknet is in training mode: the reference would run BatchNorm on batch statistics (its callers "
+                "never call .eval(), SURVEY.md F2). This path implements running-statistics BN only: call "
+                ".eval() (or set bn_running_stats_in_train=True to accept eval semantics).")
+        return inp_dim
+
+    def forward(self, x, _launch_ms=None):
+        self._check_input(x)
+        lib = _ffi.lib()
+        B = x.size(0)
+        max_batch = B if self._plan_key is None else max(B, self._plan_key[1])
+        info = self.prepare(max_batch, x.device)
+        x = x.contiguous()
+        out = torch.empty((B, info.total_rows, info.attrs), dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            _ffi.check(lib.rtod_plan_set_train_decode(self._plan, 1 if self.TRAIN else 0))
+            if _launch_ms is None:
+                _ffi.check(lib.rtod_forward(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream))
+            else:
+                _ffi.check(lib.rtod_forward_timed(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream, _launch_ms))
+        # attributes the reference sets as a side effect of forward (src/darknet.py:239-243, 260)
+        anchors = []
+        for m, blk in zip(self.module_list, self.blocks[1:]):
+            if blk["type"] == "yolo":
+                anchors.extend(m[0].anchors)
+                self.num_classes = int(blk["classes"])
+        self.anchors = anchors
+        return out
+
+    def forward_timed(self, x):
+        """Forward with a HIP-event pair around every launch; returns (out, ms per launch)."""
+        self._check_input(x)
+        info = self.prepare(x.size(0) if self._plan_key is None else max(x.size(0), self._plan_key[1]), x.device)
+        ms = (C.c_float * info.n_launches)()
+        out = self.forward(x, _launch_ms=ms)
+        return out, np.frombuffer(ms, dtype=np.float32).copy()
+
+    def read_layer(self, layer: int, batch: int) -> torch.Tensor:
+        """Dense NCHW copy of a materialised layer output of the last forward (tests/debug)."""
+        lib = _ffi.lib()
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        _ffi.check(lib.rtod_plan_layer_shape(self._plan, layer, C.byref(c), C.byref(h), C.byref(w)))
+        dev = torch.device("cuda", self._plan_key[2])
+        out = torch.empty((batch, c.value, h.value, w.value), dtype=torch.float32, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _ffi.check(lib.rtod_plan_read_layer(self._plan, layer, batch, C.c_void_p(out.data_ptr()), stream))
+        return out
+
+    @contextmanager
+    def train_mode(self):
+        """Decode without grid offsets / anchors (reference: src/darknet.py:305-314)."""
+        try:
+            self.TRAIN = True
+            yield
+        finally:
+            self.TRAIN = False

@@ -1,0 +1,133 @@
+"""Host-side mirror of the hot-path half of the reference's ``src/util.py`` on librtod.so.
+
+Same names, argument meaning and return conventions as the reference (SURVEY.md §8 b):
+
+* ``predict_transform(prediction, inp_dim, anchors, num_class, CUDA, TRAIN=False)``  src/util.py:175-239
+* ``write_results(prediction, num_class, confidence=0.6, nms_conf=0.4)``              src/util.py:242-346
+  -> float32 ``[D,8]`` tensor on prediction's device, or the Python int ``0``
+* ``confidence_mask(tensor, confidence)``                                              src/util.py:106-117
+* ``bbox_iou(box1, box2)``                                                             src/util.py:120-153
+
+All tensors must be CUDA (ROCm) float32 tensors; there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+
+_ws_cache = {}
+
+
+def _need_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s: expected a CUDA (ROCm) tensor; this build has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise ValueError("%s: expected float32, got %s" % (name, t.dtype))
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def predict_transform(prediction, inp_dim, anchors, num_class, CUDA=True, TRAIN=False) -> torch.Tensor:
+    _need_cuda(prediction, "predict_transform")
+    if prediction.dim() != 4 or prediction.size(2) != prediction.size(3):
+        raise ValueError("predict_transform: expected [B, A*(5+C), G, G], got %s" % (tuple(prediction.shape),))
+    lib = _ffi.lib()
+    B, ch, G = prediction.size(0), prediction.size(1), prediction.size(2)
+    attrs = 5 + int(num_class)
+    A = len(anchors)
+    if ch != A * attrs:
+        raise ValueError("predict_transform: %d channels != %d anchors * %d attrs" % (ch, A, attrs))
+    x = prediction.contiguous()
+    out = torch.empty((B, G * G * A, attrs), dtype=torch.float32, device=x.device)
+    anc = (C.c_float * (2 * A))(*[float(v) for a in anchors for v in a])
+    with torch.cuda.device(x.device):
+        _ffi.check(lib.rtod_predict_transform(C.c_void_p(x.data_ptr()), B, attrs, G, A, anc, int(inp_dim),
+                                              1 if TRAIN else 0, C.c_void_p(out.data_ptr()), _stream(x.device)))
+    return out
+
+
+def confidence_mask(tensor: torch.Tensor, confidence: float) -> torch.Tensor:
+    _need_cuda(tensor, "confidence_mask")
+    if tensor.dim() != 3 or tensor.size(2) < 5:
+        raise ValueError("confidence_mask: expected [B,N,>=5]")
+    x = tensor.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _ffi.check(_ffi.lib().rtod_confidence_mask(C.c_void_p(x.data_ptr()), x.size(0) * x.size(1), x.size(2),
+                                                   float(confidence), C.c_void_p(out.data_ptr()), _stream(x.device)))
+    return out
+
+
+def bbox_iou(box1: torch.Tensor, box2: torch.Tensor) -> torch.Tensor:
+    """IoU of one box against k boxes with the reference's +1 pixel convention."""
+    _need_cuda(box1, "bbox_iou")
+    _need_cuda(box2, "bbox_iou")
+    b1 = box1.reshape(-1, box1.size(-1))
+    b2 = box2.reshape(-1, box2.size(-1))
+    if b1.size(0) != 1 or b1.size(1) < 4 or b2.size(1) < 4:
+        raise NotImplementedError("bbox_iou: one box [1,>=4] against k boxes [k,>=4] (the reference's only use)")
+    b1 = b1.contiguous()
+    b2 = b2.contiguous()
+    k = b2.size(0)
+    out = torch.empty((k,), dtype=torch.float32, device=b2.device)
+    with torch.cuda.device(b2.device):
+        _ffi.check(_ffi.lib().rtod_bbox_iou(C.c_void_p(b1.data_ptr()), C.c_void_p(b2.data_ptr()), k, b2.size(1),
+                                            C.c_void_p(out.data_ptr()), _stream(b2.device)))
+    return out
+
+
+def _nms_buffers(dev, B, n, cap):
+    key = (dev.index, B, n, cap)
+    buf = _ws_cache.get(key)
+    if buf is None:
+        nbytes = C.c_size_t()
+        _ffi.check(_ffi.lib().rtod_write_results_workspace(B, n, C.byref(nbytes)))
+        ws = torch.empty((nbytes.value + 15) // 16 * 4, dtype=torch.int32, device=dev)
+        out = torch.empty((max(cap, 1), 8), dtype=torch.float32, device=dev)
+        counts = torch.zeros((2 + B + 2,), dtype=torch.int32, device=dev)
+        buf = (ws, out, counts, nbytes.value)
+        if len(_ws_cache) > 16:
+            _ws_cache.clear()
+        _ws_cache[key] = buf
+    return buf
+
+
+def write_results_async(prediction, num_class, confidence=0.6, nms_conf=0.4, cap=None):
+    """Enqueue filter + NMS; returns device tensors ``(rows[cap,8], counts)`` without synchronising.
+
+    ``counts[0]`` = D (valid rows; may exceed cap), ``counts[1]`` = candidates over the batch,
+    ``counts[2:2+B]`` = detections per image.  The buffers are reused by the next call with the
+    same shape: consume (or clone) them before calling again.
+    """
+    _need_cuda(prediction, "write_results")
+    if prediction.dim() != 3 or prediction.size(2) != 5 + int(num_class):
+        raise ValueError("write_results: expected [B,N,5+num_class], got %s" % (tuple(prediction.shape),))
+    x = prediction.contiguous()
+    B, n = x.size(0), x.size(1)
+    if cap is None:
+        cap = min(B * n, 16384)
+    ws, out, counts, nbytes = _nms_buffers(x.device, B, n, int(cap))
+    with torch.cuda.device(x.device):
+        _ffi.check(_ffi.lib().rtod_write_results(C.c_void_p(x.data_ptr()), B, n, int(num_class), float(confidence),
+                                                 float(nms_conf), C.c_void_p(out.data_ptr()), int(cap),
+                                                 C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
+                                                 _stream(x.device)))
+    return out, counts
+
+
+def write_results(prediction, num_class, confidence=0.6, nms_conf=0.4):
+    """Reference-compatible: new ``[D,8]`` tensor, an empty ``[0,8]`` tensor when candidates existed
+    but none had a non-zero class score (what the reference's concatenation yields), or int ``0``."""
+    B, n = prediction.size(0), prediction.size(1)
+    out, counts = write_results_async(prediction, num_class, confidence, nms_conf)
+    c = counts[:2].tolist()                    # one host sync, like the reference's own .tolist()/nonzero
+    D, cand = int(c[0]), int(c[1])
+    if D > out.size(0):                        # more detections than the default capacity: redo at full size
+        out, counts = write_results_async(prediction, num_class, confidence, nms_conf, cap=B * n)
+        D = int(counts[0].item())
+    if cand == 0:
+        return 0
+    return out[:D].clone()

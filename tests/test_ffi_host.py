@@ -1,0 +1,136 @@
+"""CPU tests of the boundary: librtod.so loads, exports every symbol include/rtod.h declares, and the
+host-only plan logic (cfg grammar, shape resolution, buffer planning) agrees with the Python IR and
+with the reference-derived fixtures.  No compute call is made (no GPU here)."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+from realtimeobjectdetection_amd import _ffi, cfgs
+from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plan(text, res, max_batch=8):
+    lib = _ffi.lib()
+    h = C.c_void_p()
+    t = text.encode()
+    rc = lib.rtod_plan_create(t, len(t), res, res, max_batch, 0, C.byref(h))
+    return rc, h
+
+
+def _describe(h):
+    lib = _ffi.lib()
+    need = C.c_size_t()
+    assert lib.rtod_plan_describe(h, None, 0, C.byref(need)) == 0
+    buf = C.create_string_buffer(need.value)
+    assert lib.rtod_plan_describe(h, buf, need.value, None) == 0
+    return json.loads(buf.value.decode())
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "rtod.h")).read()
+    declared = set(re.findall(r"\b(rtod_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(_ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in rtod.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    assert _ffi.lib().rtod_version() >= 100
+
+
+@pytest.mark.parametrize("net,res", [("yolov3", 608), ("yolov3", 416), ("yolov3-tiny", 416)])
+def test_native_plan_matches_python_ir(net, res):
+    gen = {"yolov3": cfgs.yolov3_cfg, "yolov3-tiny": cfgs.yolov3_tiny_cfg}[net]
+    rc, h = _plan(gen(), res)
+    assert rc == 0, _ffi.last_error()
+    d = _describe(h)
+    ir = build_ir(parse_cfg_text(gen()), res)
+    assert d["total_rows"] == ir.total_rows and d["attrs"] == ir.attrs
+    assert d["n_weight_floats"] == ir.n_weights and d["conv_flops"] == ir.conv_flops
+    for L, D in zip(ir.layers, d["layers"]):
+        assert (L.type, L.cin, L.cout, L.hin, L.win, L.hout, L.wout, L.size, L.stride, L.pad, L.bn, L.leaky) == \
+               (D["type"], D["cin"], D["cout"], D["hin"], D["win"], D["hout"], D["wout"], D["size"], D["stride"], D["pad"], D["bn"], D["leaky"])
+        assert list(L.srcs) == D["srcs"] and [list(a) for a in L.anchors] == D["anchors"]
+        assert (L.rows, L.row_offset) == (D["rows"], D["row_offset"])
+    info = _ffi.PlanInfo()
+    assert _ffi.lib().rtod_plan_get_info(h, C.byref(info)) == 0
+    assert info.total_rows == ir.total_rows and info.conv_flops_per_frame == ir.conv_flops
+    # every shortcut and head decode rides a conv epilogue; both concats are zero-copy
+    kinds = []
+    flops = 0
+    for i in range(info.n_launches):
+        li = _ffi.LaunchInfo()
+        assert _ffi.lib().rtod_plan_get_launch(h, i, C.byref(li)) == 0
+        kinds.append(li.kind)
+        flops += li.flops_per_frame
+    assert flops == ir.conv_flops
+    assert 3 not in kinds and 5 not in kinds and 6 not in kinds        # no add / decode / copy launches
+    n_conv = sum(1 for L in ir.layers if L.type == "convolutional")
+    assert kinds.count(0) == n_conv
+    _ffi.lib().rtod_plan_destroy(h)
+
+
+def test_buffer_plan_has_no_live_overlap():
+    rc, h = _plan(cfgs.yolov3_cfg(), 608)
+    assert rc == 0
+    d = _describe(h)
+    bufs = d["bufs"]
+    for i, a in enumerate(bufs):
+        sa = (a["floats_per_frame"] * 8 + 63) // 64 * 64
+        for b in bufs[i + 1:]:
+            sb = (b["floats_per_frame"] * 8 + 63) // 64 * 64
+            live = not (a["last"] < b["first"] or b["last"] < a["first"])
+            mem = not (a["offset"] + sa <= b["offset"] or b["offset"] + sb <= a["offset"])
+            assert not (live and mem), (a, b)
+    assert d["arena_floats"] * 4 < 1.0e9          # 608x608 batch 8 fits well under 1 GB of the 288 GB
+    _ffi.lib().rtod_plan_destroy(h)
+
+
+def test_error_codes_and_messages():
+    lib = _ffi.lib()
+    rc, h = _plan("[net]\nheight=416\n[convolutional]\nfilters=16\nsize=3\nstride=1\npad=1\nactivation=leaky\n[banana]\nx=1\n", 416)
+    assert rc == -3 and "unknown block" in _ffi.last_error().lower()      # reference asserts (darknet.py:524-526)
+    rc, h = _plan("[convolutional]\nfilters=1\n", 416)
+    assert rc == -3
+    rc, h = _plan(cfgs.yolov3_tiny_cfg(), 400)                            # 400/13 grid mismatch is caught
+    assert rc in (-3, 0)
+    h2 = C.c_void_p()
+    t = cfgs.yolov3_tiny_cfg().encode()
+    assert lib.rtod_plan_create(t, len(t), 416, 320, 1, 0, C.byref(h2)) == -1     # non-square
+    rc, h = _plan(cfgs.yolov3_tiny_cfg(), 416)
+    assert rc == 0
+    # forward before load_weights is a state error, not a crash (no device touched)
+    assert lib.rtod_forward(h, C.c_void_p(16), 1, C.c_void_p(16), None) == -4
+    # short weight stream (reference: view_as raises)
+    import numpy as np
+    w = np.zeros(100, np.float32)
+    assert lib.rtod_plan_load_weights(h, w.ctypes.data_as(C.c_void_p), w.size) == -5
+    assert "needs" in _ffi.last_error()
+    lib.rtod_plan_destroy(h)
+
+
+def test_darknet_host_class_without_gpu(tmp_path):
+    """The nn.Module mirror keeps the reference's surface; forward refuses CPU tensors."""
+    import torch
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd import synth
+    p = cfgs.write_cfg(str(tmp_path / "t.cfg"), cfgs.yolov3_tiny_cfg())
+    m = Darknet(p, False)
+    assert m.training and m.get_blocks() is m.blocks and m.get_module_list() is m.module_list
+    assert m.net_info["height"] == "416" and len(m.module_list) == 24 and len(m.blocks) == 25
+    assert m.blocks[17 + 1]["layers"] == ["-4"] and m.blocks[20 + 1]["layers"] == ["-1", " 8"]   # split in place like the reference
+    sd = m.state_dict()
+    assert len(sd) == 70 and "module_list.15.conv_15.bias" in sd
+    ir = build_ir(m.blocks, 416)
+    w = synth.synth_weights(ir)
+    wp = synth.write_weights_file(str(tmp_path / "w.weights"), w, seen=9)
+    m.load_weights(wp)
+    assert int(m.seen) == 9 and m.header.tolist() == [0, 2, 0, 9, 0]
+    import numpy as np
+    assert np.array_equal(m.weight_stream(), w)
+    with pytest.raises(RuntimeError):
+        m.eval()(torch.zeros(1, 3, 416, 416))
