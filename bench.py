@@ -33,10 +33,11 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0        # dense f16/bf16 MFMA; the split kernel issues 3 products per algorithmic MAC
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(res, device, max_batch):
+def build_model(res, device, max_batch, precision):
     from realtimeobjectdetection_amd import cfgs, synth
     from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
     from realtimeobjectdetection_amd.darknet import Darknet
@@ -48,6 +49,7 @@ def build_model(res, device, max_batch):
         wpath = synth.write_weights_file(os.path.join(d, "yolov3.weights"), w)
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
+        m.precision = precision
         m.load_weights(wpath)
     m.prepare(max_batch, device)
     return m, ir, w, cfg_text
@@ -122,8 +124,12 @@ def roofline_from_launches(model, x, steps):
                   "tflops": round(float(li.flops_per_frame) * B / (float(ms) * 1e-3) / 1e12, 2) if li.kind == 0 and ms > 0 else None,
                   "gbs": round((float(li.bytes_per_frame) * B + li.weight_bytes) / (float(ms) * 1e-3) / 1e9, 1) if ms > 0 else None}
                  for li, ms in zip(infos, tot)]
-    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+    split = "f16s3" in name
+    peak = round(PEAK_F16_MFMA_TFLOPS / 3.0, 1) if split else PEAK_FP32_MFMA_TFLOPS
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "peak_note": ("algorithmic FLOPs; each MAC issues 3 f16 MFMA products, peak = 2500/3" if split
+                          else "exact-fp32 MFMA v_mfma_f32_32x32x2_f32"),
             "launches_per_step": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 5),
             "flops_per_launch": g["flops"] / g["launches"],
             "all_conv_tflops": round(sum(v["flops"] for v in groups.values()) / (conv_ms * 1e-3) / 1e12, 2),
@@ -140,6 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--conf", type=float, default=0.6)
     ap.add_argument("--nms", type=float, default=0.5)
+    ap.add_argument("--precision", default=os.environ.get("RTOD_PRECISION", "f16s3"), choices=["fp32", "f16s3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
@@ -165,7 +172,7 @@ def main():
     from realtimeobjectdetection_amd import synth
     from realtimeobjectdetection_amd.util import write_results_async
     B, R = args.batch, args.res
-    model, ir, w, cfg_text = build_model(R, dev, B)
+    model, ir, w, cfg_text = build_model(R, dev, B, args.precision)
     # this rank's frame shard: frames [rank*B, (rank+1)*B) of the global synthetic stream
     x = torch.from_numpy(synth.synth_frames(B, R, seed=synth.FRAME_SEED + rank)).to(dev)
     CAP = 4096                                          # rows gathered per rank (fixed-capacity, no host sync)
@@ -225,9 +232,10 @@ def main():
             "metric": "frames/sec YOLOv3 %dx%d bs=%d (Darknet.forward + write_results)" % (R, R, B),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "YOLOv3 cfg %dx%d batch=%d per GPU, exact-fp32 MFMA conv + fused head + GPU NMS (BASELINE configs[%d])"
-                                   % (R, R, B, 2 if R == 608 else 1),
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x2-split (3 MFMA products, f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "YOLOv3 cfg %dx%d batch=%d per GPU, %s MFMA conv + fused head + GPU NMS (BASELINE configs[%d])"
+                                   % (R, R, B, "exact-fp32" if args.precision == "fp32" else "split-f16", 2 if R == 608 else 1),
+                       "precision": args.precision,
                        "frames_per_step": world * B, "parallelism": "frame-shard x%d" % world,
                        "conf": args.conf, "nms": args.nms, "detections_last_step": n_det, "candidates_last_step": n_cand,
                        "conv_gflop_per_frame": round(ir.conv_flops / 1e9, 3),

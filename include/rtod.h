@@ -80,6 +80,13 @@ int rtod_plan_get_launch(const rtod_plan* plan, int index, rtod_launch_info* out
 /* JSON description of the resolved layer IR (tests compare it with the Python IR / reference). */
 int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* needed);
 const char* rtod_conv_variant_name(int variant);
+/* Arithmetic of the convolutions (call before rtod_plan_load_weights):
+ *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-level fmaf chains, the parity anchor;
+ *   1  split-precision f16 MFMA: a*w ~= ah*wh + ah*wl + al*wh with fp32 accumulation (22-bit
+ *      operands, error ~2x fp32 per layer), 16x the MFMA rate per product.  Activations live in
+ *      HBM as f16 hi/lo planes (x8 pre-scaled): needs |activation| < 8188, every conv after the
+ *      stem with Cin % 32 == 0, no maxpool / stand-alone shortcut; otherwise RTOD_E_CFG. */
+int rtod_plan_set_precision(rtod_plan* plan, int mode);
 
 /* replaces Darknet.load_weights                              src/darknet.py:316-410
  * `w` is the float payload of a Darknet .weights file (after the 5xint32 header), host memory:

@@ -83,9 +83,58 @@ __global__ void upsample2x_kernel(View in, View out, int B) {
     }
 }
 
+// split-format variant: 8 channels (16 B of each plane) per thread; interpolation is linear, so it runs
+// directly on hi+lo (the SPLIT_SCALE factor carries through) and the result is re-split.
+typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
+__global__ void upsample2x_split_kernel(View in, View out, int B) {
+    const int C8 = in.C / 8;
+    const int64_t total = (int64_t)B * out.H * out.W * C8;
+    const _Float16* ib = reinterpret_cast<const _Float16*>(in.base);
+    _Float16* ob = reinterpret_cast<_Float16*>(out.base);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C8) * 8;
+        int64_t p = t / C8;
+        const int ox = (int)(p % out.W); p /= out.W;
+        const int oy = (int)(p % out.H);
+        const int b = (int)(p / out.H);
+        int y0, y1, x0, x1; float wy1, wx1;
+        up_coord(oy, in.H, y0, y1, wy1);
+        up_coord(ox, in.W, x0, x1, wx1);
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        const int64_t rb = (int64_t)b * in.H;
+        auto ld = [&](int y, int x, float* v) {
+            const _Float16* q = ib + ((rb + y) * in.W + x) * 2 * in.ldc + in.coff + c;
+            const f16x8a h = *reinterpret_cast<const f16x8a*>(q);
+            const f16x8a l = *reinterpret_cast<const f16x8a*>(q + in.ldc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
+        };
+        float v00[8], v01[8], v10[8], v11[8];
+        ld(y0, x0, v00); ld(y0, x1, v01); ld(y1, x0, v10); ld(y1, x1, v11);
+        f16x8a rh, rl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float r = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+            const _Float16 h = (_Float16)r;
+            rh[e] = h; rl[e] = (_Float16)(r - (float)h);
+        }
+        _Float16* q = ob + (((int64_t)b * out.H + oy) * out.W + ox) * 2 * out.ldc + out.coff + c;
+        *reinterpret_cast<f16x8a*>(q) = rh;
+        *reinterpret_cast<f16x8a*>(q + out.ldc) = rl;
+    }
+}
+
 static bool view_ok4(const View& v) { return v.base && v.C % 4 == 0 && v.ldc % 4 == 0 && v.coff % 4 == 0; }
 
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s) {
+    if (in.split != out.split) { set_error("upsample2x: mixed formats"); return RTOD_E_ARG; }
+    if (in.split) {
+        if (!in.base || !out.base || in.C % 8 || in.ldc % 8 || in.coff % 8 || out.ldc % 8 || out.coff % 8 ||
+            out.H != 2 * in.H || out.W != 2 * in.W || out.C != in.C) { set_error("upsample2x(split): bad views"); return RTOD_E_ARG; }
+        const int64_t total = (int64_t)B * out.H * out.W * (in.C / 8);
+        hipLaunchKernelGGL(upsample2x_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B);
+        return hip_fail(hipGetLastError(), "upsample2x(split) launch");
+    }
     if (!view_ok4(in) || !view_ok4(out) || out.H != 2 * in.H || out.W != 2 * in.W || out.C != in.C) {
         set_error("upsample2x: bad views"); return RTOD_E_ARG;
     }
@@ -109,6 +158,7 @@ __global__ void add_kernel(View a, View b, View out, int B) {
 }
 
 int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s) {
+    if (a.split || b.split || out.split) { set_error("add: split-format views unsupported (shortcut must fuse into a conv)"); return RTOD_E_ARG; }
     if (!view_ok4(a) || !view_ok4(b) || !view_ok4(out) || a.C != b.C || a.C != out.C || a.H != b.H || a.W != b.W) {
         set_error("add: bad views"); return RTOD_E_ARG;
     }
@@ -130,6 +180,7 @@ __global__ void copy_kernel(View a, View out, int B) {
 }
 
 int launch_copy(const View& a, const View& out, int B, hipStream_t s) {
+    if (a.split || out.split) { set_error("copy: split-format views unsupported (route concat must be zero-copy)"); return RTOD_E_ARG; }
     if (!view_ok4(a) || !view_ok4(out) || a.C != out.C || a.H != out.H || a.W != out.W) {
         set_error("copy: bad views"); return RTOD_E_ARG;
     }
@@ -165,6 +216,7 @@ __global__ void maxpool_kernel(View in, View out, int B, int size, int stride) {
 }
 
 int launch_maxpool(const View& in, const View& out, int B, int size, int stride, hipStream_t s) {
+    if (in.split || out.split) { set_error("maxpool: split-format views unsupported (use precision fp32)"); return RTOD_E_ARG; }
     if (!view_ok4(in) || !view_ok4(out) || in.C != out.C || size < 1 || stride < 1) { set_error("maxpool: bad views"); return RTOD_E_ARG; }
     const int64_t total = (int64_t)B * out.H * out.W * (in.C / 4);
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B, size, stride);
@@ -181,7 +233,13 @@ __global__ void view_to_nchw_kernel(View in, int B, float* __restrict__ out) {
         const int y = (int)(p % in.H); p /= in.H;
         const int c = (int)(p % in.C);
         const int b = (int)(p / in.C);
-        out[t] = in.base[(((int64_t)b * in.H + y) * in.W + x) * in.ldc + in.coff + c];
+        const int64_t pix = ((int64_t)b * in.H + y) * in.W + x;
+        if (in.split) {
+            const _Float16* q = reinterpret_cast<const _Float16*>(in.base) + pix * 2 * in.ldc + in.coff + c;
+            out[t] = ((float)q[0] + (float)q[in.ldc]) * (1.0f / SPLIT_SCALE);
+        } else {
+            out[t] = in.base[pix * in.ldc + in.coff + c];
+        }
     }
 }
 

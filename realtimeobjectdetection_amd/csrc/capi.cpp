@@ -92,8 +92,18 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 }
 
 const char* rtod_conv_variant_name(int variant) {
+    if (variant >= 100 && variant < 100 + HV_COUNT) return conv_f16s3_variant_info(variant - 100).name;
     if (variant < 0 || variant >= CV_COUNT) return "";
     return conv_variant_info(variant).name;
+}
+
+int rtod_plan_set_precision(rtod_plan* plan, int mode) {
+    if (!plan || (mode != 0 && mode != 1)) { set_error("set_precision: mode must be 0 (fp32) or 1 (f16 split)"); return RTOD_E_ARG; }
+    if (plan->p.d_weights) { set_error("set_precision: must be called before rtod_plan_load_weights"); return RTOD_E_STATE; }
+    if (mode == 1) { const int rc = plan->p.check_split_supported(); if (rc) return rc; }
+    plan->p.precision = mode;
+    plan->p.layout_weights();
+    return RTOD_OK;
 }
 
 int rtod_plan_load_weights(rtod_plan* plan, const float* w, size_t n_floats) {

@@ -175,6 +175,13 @@ void conv_igemm_f32_kernel(const ConvArgs a, const int grid_m, const int grid_n)
                     const int gy = cell / a.dec.G, gx = cell - gy * a.dec.G;
                     v = decode_value(a.dec, v, n, gx, gy);
                     a.out[(int64_t)b * a.dec.img_stride + a.dec.head_off + (int64_t)cell * a.Cout + n] = v;
+                } else if (a.out_split) {
+                    // split format for a following conv_igemm_f16s3 layer: 8*v as f16 hi + f16 lo planes
+                    const float v8 = v * SPLIT_SCALE;
+                    const _Float16 h = (_Float16)v8;
+                    _Float16* oh = reinterpret_cast<_Float16*>(a.out) + (int64_t)m * 2 * a.out_ldc + a.out_coff + n;
+                    oh[0] = h;
+                    oh[a.out_ldc] = (_Float16)(v8 - (float)h);
                 } else {
                     a.out[(int64_t)m * a.out_ldc + a.out_coff + n] = v;
                 }

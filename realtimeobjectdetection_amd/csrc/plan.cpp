@@ -417,14 +417,51 @@ int Plan::plan_buffers() {
         bufs[b].floats_per_frame = (int64_t)bufs[b].C * bufs[b].H * bufs[b].W;
     }
     assign_arena();
-    // packed weight arena layout
+    layout_weights();
+    return RTOD_OK;
+}
+
+bool Plan::uses_split(const Layer& L, int cin_p) const {
+    return precision == 1 && L.index > 0;      // the stem stays on the exact-fp32 kernel and writes the split format
+}
+
+int Plan::check_split_supported() const {
+    // precision 1 keeps every activation in the split f16 format: every conv but the stem must read
+    // 32-channel K-chunks, every shortcut / head must ride a conv epilogue, concats must be zero-copy
+    for (const auto& l : launches) {
+        if (l.kind == LK_ADD || l.kind == LK_COPY || l.kind == LK_MAXPOOL || l.kind == LK_DECODE) {
+            set_error("precision f16s3 unsupported for this cfg (layer %d needs a stand-alone %s kernel); use fp32", l.layer,
+                      l.kind == LK_ADD ? "add" : l.kind == LK_COPY ? "copy" : l.kind == LK_MAXPOOL ? "maxpool" : "decode");
+            return RTOD_E_CFG;
+        }
+        if (l.kind == LK_CONV && l.layer > 0) {
+            const Layer& L = layers[l.layer];
+            if (L.cin % 32 || L.cout % 8 * (l.out_layer != -2)) {
+                set_error("precision f16s3 unsupported for this cfg (layer %d: Cin=%d Cout=%d); use fp32", l.layer, L.cin, L.cout);
+                return RTOD_E_CFG;
+            }
+        }
+    }
+    for (const auto& b : bufs) if (b.C % 8 && &b != &bufs[input_buf]) { set_error("precision f16s3: a buffer has %d channels (not a multiple of 8)", b.C); return RTOD_E_CFG; }
+    return RTOD_OK;
+}
+
+void Plan::layout_weights() {
     packed_floats = 0;
     for (auto& pc : convs) {
-        pc.w_off = packed_floats; packed_floats += (int64_t)pc.Npad * pc.Kpad;
+        const Layer& L = layers[pc.layer];
+        pc.split = uses_split(L, pc.cin_p);
+        const int64_t panel = (int64_t)pc.Npad * pc.Kpad;
+        if (pc.split) {
+            pc.w_off = packed_floats; packed_floats += panel / 2;       // f16 hi plane
+            pc.wl_off = packed_floats; packed_floats += panel / 2;      // f16 lo plane
+            pc.s_off = packed_floats; packed_floats += pc.Npad;
+        } else {
+            pc.w_off = packed_floats; packed_floats += panel;
+        }
         pc.b_off = packed_floats; packed_floats += pc.Npad;
         packed_floats = (packed_floats + 63) / 64 * 64;
     }
-    return RTOD_OK;
 }
 
 void Plan::assign_arena() {
@@ -463,12 +500,42 @@ View Plan::view_of(int layer) const {
     const Layer& L = layers[resolve_alias(layers, layer)];
     if (L.buf < 0) return v;
     const Buffer& b = bufs[L.buf];
+    v.split = precision == 1 ? 1 : 0;
     v.base = d_arena ? d_arena + b.offset : nullptr;
     v.ldc = b.C; v.coff = L.coff; v.C = L.cout; v.H = L.hout; v.W = L.wout;
     return v;
 }
 
 // ------------------------------------------------------------------------------------- weights
+static uint16_t f32_to_f16_rn(float f) {           // IEEE binary16, round to nearest even, host side
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);               // rounds to >= 65520 -> inf
+    if (x < 0x33000001u) return (uint16_t)sign;                             // < 2^-25 -> 0
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                          // subnormal halves lose extra bits
+    uint32_t half_m = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_m & 1))) ++half_m;
+    uint32_t out;
+    if (e < -14) out = half_m;                                               // subnormal (may carry into normal)
+    else out = ((uint32_t)(e + 15) << 10) + (half_m - 0x400u);               // carry propagates into the exponent
+    return (uint16_t)(sign | out);
+}
+static float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1F; const uint32_t m = h & 0x3FFu;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 0x400u), e - 25);
+    uint32_t x; memcpy(&x, &v, 4); x |= sign; memcpy(&v, &x, 4);
+    return v;
+}
+
 int Plan::load_weights(const float* w, size_t n) {
     if (!w) { set_error("load_weights: null pointer"); return RTOD_E_ARG; }
     if ((int64_t)n < n_weight_floats) {
@@ -496,14 +563,43 @@ int Plan::load_weights(const float* w, size_t n) {
             for (int o = 0; o < C; ++o) bias[o] = p[o];
             p += C;
         }
-        float* wp = packed.data() + pc.w_off;
-        for (int o = 0; o < C; ++o)
-            for (int c = 0; c < cin; ++c)
-                for (int ky = 0; ky < k; ++ky)
-                    for (int kx = 0; kx < k; ++kx) {
-                        const float v = p[(((int64_t)o * cin + c) * k + ky) * k + kx];          // OIHW
-                        wp[(int64_t)o * pc.Kpad + (ky * k + kx) * pc.cin_p + c] = (float)((double)v * scale[o]);
-                    }
+        if (!pc.split) {
+            float* wp = packed.data() + pc.w_off;
+            for (int o = 0; o < C; ++o)
+                for (int c = 0; c < cin; ++c)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const float v = p[(((int64_t)o * cin + c) * k + ky) * k + kx];          // OIHW
+                            wp[(int64_t)o * pc.Kpad + (ky * k + kx) * pc.cin_p + c] = (float)((double)v * scale[o]);
+                        }
+        } else {
+            // f16 hi/lo planes.  Per output channel a power-of-two pre-scale 2^e puts max|w| in
+            // [2^12, 2^13): low parts of weights down to 2^-16 of the channel maximum stay normal f16.
+            uint16_t* wh = reinterpret_cast<uint16_t*>(packed.data() + pc.w_off);
+            uint16_t* wl = reinterpret_cast<uint16_t*>(packed.data() + pc.wl_off);
+            float* inv = packed.data() + pc.s_off;
+            for (int o = 0; o < pc.Npad; ++o) inv[o] = 1.0f / ACT_SCALE_F16S3;
+            const int64_t per_o = (int64_t)cin * k * k;
+            for (int o = 0; o < C; ++o) {
+                double mx = 0.0;
+                for (int64_t q = 0; q < per_o; ++q) mx = std::max(mx, std::fabs((double)p[o * per_o + q] * scale[o]));
+                int e = 0;
+                if (mx > 0.0) { int ex; std::frexp(mx, &ex); e = 13 - ex; }      // mx * 2^e in [2^12, 2^13)
+                e = std::max(-24, std::min(40, e));
+                const double ps = std::ldexp(1.0, e);
+                inv[o] = (float)(std::ldexp(1.0, -e) / (double)ACT_SCALE_F16S3);
+                for (int c = 0; c < cin; ++c)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const float v = (float)((double)p[(((int64_t)o * cin + c) * k + ky) * k + kx] * scale[o]);   // the fp32 folded weight
+                            const float vs = (float)((double)v * ps);                                                    // exact (power of two)
+                            const uint16_t h = f32_to_f16_rn(vs);
+                            const uint16_t l = f32_to_f16_rn(vs - f16_to_f32(h));
+                            const int64_t idx = (int64_t)o * pc.Kpad + (ky * k + kx) * pc.cin_p + c;
+                            wh[idx] = h; wl[idx] = l;
+                        }
+            }
+        }
     }
     if (!d_weights) RTOD_HIP(hipMalloc((void**)&d_weights, sizeof(float) * (size_t)packed_floats));
     if (!d_arena) {
@@ -525,6 +621,17 @@ int Plan::choose_variant(const Layer& L, int batch) const {
     const int64_t M = (int64_t)batch * L.hout * L.wout;
     const int64_t big = ((M + 127) / 128) * ((L.cout + 127) / 128);
     return big >= 512 ? CV_128x128 : CV_64x64;     // keep >= 2 workgroups per CU in flight
+}
+
+int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
+    const char* force = getenv("RTOD_F16S3_VARIANT");
+    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < HV_COUNT) return v; }
+    if (L.cout <= 64) return HV_128x64;
+    const int64_t M = (int64_t)batch * L.hout * L.wout;
+    const int64_t gn = (L.cout + 127) / 128;
+    if (((M + 127) / 128) * gn >= 512) return HV_128x128;
+    if (((M + 63) / 64) * gn >= 512) return HV_64x128;
+    return HV_64x64;
 }
 
 int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms) {
@@ -554,6 +661,13 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
                 a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
                 a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
+                a.in_bytes = (unsigned)std::min<int64_t>((int64_t)batch * in.H * in.W * in.ldc * 4, 0xFFFFFFFFll);
+                a.w_bytes = (unsigned)std::min<int64_t>((int64_t)pc.Npad * pc.Kpad * 2, 0xFFFFFFFFll);
+                if (pc.split) {
+                    a.w_hi = reinterpret_cast<const _Float16*>(d_weights + pc.w_off);
+                    a.w_lo = reinterpret_cast<const _Float16*>(d_weights + pc.wl_off);
+                    a.inv_scale = d_weights + pc.s_off;
+                }
                 a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
                 a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
                 if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
@@ -561,14 +675,14 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 else {
                     const View o = view_of(l.out_layer);
                     if (!o.base || o.C != L.cout || o.H != L.hout || o.W != L.wout) { set_error("forward: layer %d output view mismatch", l.layer); return RTOD_E_STATE; }
-                    a.out = o.base; a.out_ldc = o.ldc; a.out_coff = o.coff;
+                    a.out = o.base; a.out_ldc = o.ldc; a.out_coff = o.coff; a.out_split = o.split;
                 }
                 if (l.in2_layer >= 0) {
                     const View r = view_of(l.in2_layer);
                     if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
                     a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
                 }
-                rc = launch_conv(a, choose_variant(L, batch), s);
+                rc = pc.split ? launch_conv_f16s3(a, choose_variant_f16s3(L, batch), s) : launch_conv(a, choose_variant(L, batch), s);
                 break;
             }
             case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;
@@ -609,7 +723,7 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
     const int64_t in_b = (int64_t)L.hin * L.win * L.cin * 4, out_b = (int64_t)L.hout * L.wout * L.cout * 4;
     switch (l.kind) {
         case LK_CONV:
-            o->variant = choose_variant(L, batch);
+            o->variant = convs[l.conv_slot].split ? 100 + choose_variant_f16s3(L, batch) : choose_variant(L, batch);
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
             o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
             o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);

@@ -53,6 +53,8 @@ struct PackedConv {
     int layer = 0;
     int cin_p = 0, K = 0, Kpad = 0, Npad = 0;
     int64_t w_off = 0, b_off = 0;     // float offsets into the device weight arena
+    bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
+    int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
 };
 
 struct Plan {
@@ -70,6 +72,7 @@ struct Plan {
     float* d_weights = nullptr;
     bool weights_loaded = false;
     int train_decode = 0;
+    int precision = 0;         // 0 = exact fp32 MFMA, 1 = f16 hi/lo split (3 products)
     bool keep_all = false;     // debug: no arena reuse, every layer output stays readable after forward
     std::vector<hipEvent_t> events;
 
@@ -78,10 +81,14 @@ struct Plan {
     int resolve_shapes();
     int plan_buffers();
     void assign_arena();
+    void layout_weights();
+    bool uses_split(const Layer& L, int cin_p) const;
+    int check_split_supported() const;
     int load_weights(const float* w, size_t n);
     int forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms);
     View view_of(int layer) const;            // resolves aliases; base == nullptr if not materialised
     int choose_variant(const Layer& L, int batch) const;
+    int choose_variant_f16s3(const Layer& L, int batch) const;
     std::string describe() const;
     void fill_launch_info(int idx, rtod_launch_info* o, int batch) const;
 };

@@ -21,6 +21,7 @@ int hip_fail(hipError_t e, const char* what);
 
 // NHWC view of an activation: element (b,y,x,c) at base[((b*H + y)*W + x)*ldc + coff + c]
 struct View {
+    int split = 0;     // 0: fp32 NHWC; 1: split f16 hi/lo planes per pixel (conv_igemm_f16s3.hip), same bytes
     float* base = nullptr;
     int64_t ldc = 0;   // floats between consecutive pixels (>= C: concat buffers are wider)
     int coff = 0;      // first channel of this view inside the pixel
@@ -54,12 +55,25 @@ struct ConvArgs {
     const float* res = nullptr; int64_t res_ldc = 0; int res_coff = 0;   // fused shortcut
     int leaky = 0;
     DecodeArgs dec;
+    // split-precision path (conv_igemm_f16s3): pre-split, pre-scaled f16 weight planes [Npad][Kpad]
+    const _Float16* w_hi = nullptr;
+    const _Float16* w_lo = nullptr;
+    const float* inv_scale = nullptr;           // [Npad]: 1 / (2^e_n * SPLIT_SCALE)
+    unsigned in_bytes = 0, w_bytes = 0;         // extents of the input buffer / one weight plane (buffer-load range check)
+    int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
 };
+
+// Split activation format: value * SPLIT_SCALE stored as f16 hi + f16 lo planes per pixel.
+constexpr float SPLIT_SCALE = 8.0f;
+constexpr float ACT_SCALE_F16S3 = SPLIT_SCALE;
 
 enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, CV_COUNT };
 struct ConvVariantInfo { int bm, bn; const char* name; };
 const ConvVariantInfo& conv_variant_info(int v);
 int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
+enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_COUNT };
+const ConvVariantInfo& conv_f16s3_variant_info(int v);
+int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);

@@ -20,6 +20,7 @@ enabled explicitly.
 """
 import ctypes as C
 import json
+import os
 from contextlib import contextmanager
 
 import numpy as np
@@ -78,6 +79,7 @@ class Darknet(nn.Module):
         self.CUDA = CUDA
         self.TRAIN = False
         self.bn_running_stats_in_train = False
+        self.precision = os.environ.get("RTOD_PRECISION", "auto")   # "fp32" (exact MFMA) | "f16s3" (split f16, 3 products) | "auto"
         self.keep_all_layers = False      # debug: no activation-arena reuse (read_layer after forward)
         self._cfg_text = _blocks_to_cfg_text(self.blocks)
         self._plan = None
@@ -214,7 +216,9 @@ class Darknet(nn.Module):
             device = torch.cuda.current_device()
         device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         inp_dim = int(self.net_info["height"])
-        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers))
+        if self.precision not in ("fp32", "f16s3", "auto"):
+            raise ValueError("Darknet.precision must be 'fp32', 'f16s3' or 'auto'")
+        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers), self.precision)
         if self._plan is None or self._plan_key != key:
             self._destroy_plan()
             h = C.c_void_p()
@@ -223,6 +227,20 @@ class Darknet(nn.Module):
             self._plan, self._plan_key = h, key
             if self.keep_all_layers:
                 _ffi.check(lib.rtod_plan_set_keep_all_layers(self._plan, 1))
+            # "auto": the split-f16 kernels when the cfg supports them (yolov3 does; cfgs with maxpool or
+            # Cin % 32 != 0 such as yolov3-tiny do not), else the exact-fp32 MFMA kernels.  Both are HIP paths.
+            if self.precision == "fp32":
+                self.active_precision = "fp32"
+            else:
+                rc = lib.rtod_plan_set_precision(self._plan, 1)
+                if rc == 0:
+                    self.active_precision = "f16s3"
+                elif self.precision == "auto" and rc == -3:
+                    self.active_precision = "fp32"
+                else:
+                    _ffi.check(rc)
+            if self.active_precision == "fp32":
+                _ffi.check(lib.rtod_plan_set_precision(self._plan, 0))
             self._plan_weights_version = -1
             info = _ffi.PlanInfo()
             _ffi.check(lib.rtod_plan_get_info(self._plan, C.byref(info)))

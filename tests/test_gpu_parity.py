@@ -30,16 +30,22 @@ def rel_err(got, ref):
 _models = {}
 
 
-def gpu_model(net, res, tmp_path_factory):
+PRECISIONS = ["fp32", "f16s3"]
+
+
+def gpu_model(net, res, tmp_path_factory, precision="fp32"):
     """Darknet (HIP) with the synthetic weights, loaded through the .weights file path."""
     from realtimeobjectdetection_amd.darknet import Darknet
-    key = (net, res)
+    if precision == "f16s3" and net == "yolov3-tiny":
+        pytest.skip("yolov3-tiny (maxpool, Cin=16) is not expressible in the split-f16 format; it runs the fp32 kernels")
+    key = (net, res, precision)
     if key not in _models:
         d = tmp_path_factory.mktemp("w_%s_%d" % (net, res))
         cfg_text = NETS[net]()
         cfg_path = cfgs.write_cfg(str(d / (net + ".cfg")), cfg_text)
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
+        m.precision = precision
         ref = O.RefDarknet(cfg_text, res)
         w = synth.synth_weights(ref.ir)
         m.load_weights(synth.write_weights_file(str(d / "w.weights"), w, seen=123))
@@ -51,10 +57,11 @@ def gpu_model(net, res, tmp_path_factory):
 
 
 # ------------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("net,res,B", FWD_CASES)
-def test_forward_vs_reference_golden(golden_dir, tmp_path_factory, net, res, B):
+def test_forward_vs_reference_golden(golden_dir, tmp_path_factory, net, res, B, precision):
     g = np.load(os.path.join(golden_dir, f"fwd_{net}_{res}_b{B}.npz"))
-    m, _ = gpu_model(net, res, tmp_path_factory)
+    m, _ = gpu_model(net, res, tmp_path_factory, precision)
     x = torch.from_numpy(synth.synth_frames(B, res)).cuda()
     with torch.no_grad():
         y = m(x)
@@ -65,12 +72,13 @@ def test_forward_vs_reference_golden(golden_dir, tmp_path_factory, net, res, B):
     assert m.num_classes == 80 and len(m.anchors) == (9 if net == "yolov3" else 6)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("net,res,B", [("yolov3-tiny", 416, 1), ("yolov3", 416, 2)])
-def test_per_layer_vs_oracle(golden_dir, tmp_path_factory, net, res, B):
+def test_per_layer_vs_oracle(golden_dir, tmp_path_factory, net, res, B, precision):
     """Every materialised layer output (NHWC view read back as NCHW) against the oracle and the
     reference's per-layer probes."""
     g = np.load(os.path.join(golden_dir, f"fwd_{net}_{res}_b{B}.npz"))
-    m, ref = gpu_model(net, res, tmp_path_factory)
+    m, ref = gpu_model(net, res, tmp_path_factory, precision)
     x = torch.from_numpy(synth.synth_frames(B, res))
     m.keep_all_layers = True               # no arena reuse: every layer stays readable after forward
     with torch.no_grad():
@@ -96,11 +104,13 @@ def test_per_layer_vs_oracle(golden_dir, tmp_path_factory, net, res, B):
     m.keep_all_layers = False
 
 
-def test_frames_are_independent_and_variants_agree(tmp_path_factory):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_frames_are_independent_and_variants_agree(tmp_path_factory, precision):
     """Eval-BN frames are independent units (SURVEY.md §8 e): a frame's rows are bit-identical
     whether it runs alone or inside a batch, and under a permutation of the batch.  This is what
     makes frame-sharding across GPUs exact."""
-    m, _ = gpu_model("yolov3-tiny", 416, tmp_path_factory)
+    net = "yolov3-tiny" if precision == "fp32" else "yolov3"
+    m, _ = gpu_model(net, 416, tmp_path_factory, precision)
     x = torch.from_numpy(synth.synth_frames(5, 416)).cuda()
     with torch.no_grad():
         y5 = m(x).clone()
@@ -185,14 +195,15 @@ def test_iou_and_confidence_mask(golden_dir):
 
 
 # ------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("net,res,B", FWD_CASES)
-def test_end_to_end_detections(golden_dir, tmp_path_factory, net, res, B):
+def test_end_to_end_detections(golden_dir, tmp_path_factory, net, res, B, precision):
     """forward + write_results on the GPU.  Selection is checked bit-exactly against the oracle
     run on the *same* prediction tensor; against the reference's own detections (which came from
     the reference's forward, differing in the last bits) rows must match within tolerance except
     where a score sits within 1e-5 of a threshold."""
     from realtimeobjectdetection_amd.util import write_results
-    m, _ = gpu_model(net, res, tmp_path_factory)
+    m, _ = gpu_model(net, res, tmp_path_factory, precision)
     x = torch.from_numpy(synth.synth_frames(B, res)).cuda()
     with torch.no_grad():
         y = m(x)
@@ -212,11 +223,12 @@ def test_end_to_end_detections(golden_dir, tmp_path_factory, net, res, B):
 
 
 # ------------------------------------------------------------------------------- full size
-def test_full_size_608_b8_properties(tmp_path_factory):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_608_b8_properties(tmp_path_factory, precision):
     """BASELINE config (3): YOLOv3 608x608 batch 8.  Too big for a stored fixture, so: oracle
     comparison on a row subsample, frame independence, and NMS output invariants."""
     from realtimeobjectdetection_amd.util import write_results
-    m, ref = gpu_model("yolov3", 608, tmp_path_factory)
+    m, ref = gpu_model("yolov3", 608, tmp_path_factory, precision)
     x_cpu = torch.from_numpy(synth.synth_frames(8, 608))
     x = x_cpu.cuda()
     with torch.no_grad():
@@ -265,6 +277,25 @@ def test_fails_loudly_without_gpu_tensors_or_in_train_mode(tmp_path_factory):
         predict_transform(torch.zeros(1, 255, 13, 13), 416, [(1, 2)] * 3, 80, False)
 
 
+def test_precision_auto_and_unsupported(tmp_path_factory):
+    """'auto' picks the split-f16 kernels for yolov3 and the exact-fp32 kernels for yolov3-tiny;
+    forcing f16s3 on a cfg it cannot express fails loudly."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd._ffi import RtodError
+    d = tmp_path_factory.mktemp("auto")
+    x = torch.from_numpy(synth.synth_frames(1, 416)).cuda()
+    for net, want in (("yolov3-tiny", "fp32"), ("yolov3", "f16s3")):
+        m = Darknet(cfgs.write_cfg(str(d / (net + ".cfg")), NETS[net]()), True).eval()
+        assert m.precision == "auto"
+        with torch.no_grad():
+            m(x)
+        assert m.active_precision == want
+    m = Darknet(cfgs.write_cfg(str(d / "t2.cfg"), NETS["yolov3-tiny"]()), True).eval()
+    m.precision = "f16s3"
+    with pytest.raises(RtodError):
+        m(x)
+
+
 def test_state_dict_roundtrip(tmp_path_factory):
     """Checkpoints with the reference's key names load and give the same output (detect.py:188-189)."""
     from realtimeobjectdetection_amd.darknet import Darknet
@@ -276,6 +307,7 @@ def test_state_dict_roundtrip(tmp_path_factory):
     cfg_path = cfgs.write_cfg(str(d / "t.cfg"), cfgs.yolov3_tiny_cfg())
     m2 = Darknet(cfg_path, True).eval()
     m2.net_info["height"] = 416
+    m2.precision = m.precision
     m2.load_state_dict(sd)
     m2.cuda()
     x = torch.from_numpy(synth.synth_frames(1, 416)).cuda()
