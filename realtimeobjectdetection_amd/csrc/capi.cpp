@@ -73,7 +73,7 @@ int rtod_plan_get_info(const rtod_plan* plan, rtod_plan_info* o) {
 
 int rtod_plan_get_launch(const rtod_plan* plan, int index, rtod_launch_info* out) {
     if (!plan || !out || index < 0 || index >= (int)plan->p.launches.size()) { set_error("plan_get_launch: bad index"); return RTOD_E_ARG; }
-    plan->p.fill_launch_info(index, out, plan->p.max_batch);
+    plan->p.fill_launch_info(index, out, plan->p.tuned.empty() ? plan->p.max_batch : plan->p.tuned.rbegin()->first);
     return RTOD_OK;
 }
 

@@ -23,6 +23,7 @@
 // advanced in scalar registers; loads are raw buffer loads whose per-lane voffset is
 // pixel-origin + tap offset, forced out of range (-> zeros) for padding taps and rows >= M.
 #include "rtod_internal.h"
+#include <cstdlib>
 
 namespace rtod {
 
@@ -52,20 +53,41 @@ __device__ __forceinline__ float h_decode(const DecodeArgs& d, float v, int n, i
     return (expf(v) * anc) * d.stride;
 }
 
+// Raw buffer load issued through inline asm so that hipcc's s_waitcnt insertion does not see it: the
+// main loop keeps two K-chunks of loads in flight across barriers and waits with hand-counted
+// vmcnt(N) (cdna guide 5.7: loads hidden from the compiler need their own counted wait, and every
+// destination must be named by the wait statement before its first use).
+__device__ __forceinline__ u32x4 asm_buffer_load_b128(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+    return v;
+}
+
+constexpr int epi_row_group(int bm, int wm, int rg_max) {
+    int best = wm;
+    for (int r = wm; r <= bm && r <= rg_max; r += wm) if (bm % r == 0) best = r;
+    return best;
+}
+
 template <int ASL, int BSL>
 struct StageRegs {
     u32x4 ah[ASL], al[ASL], bh[BSL], bl[BSL];
 };
 
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)      // <= 256 registers: two workgroups per CU
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 8 ? 2 : ((BM / WM) * (BN / WN) == 6 ? 3 : 2)))
+// second argument = waves per SIMD the register budget must admit: 8-wave tiles run one workgroup per CU
+// (2 waves/SIMD), 6-wave tiles two workgroups (3 waves/SIMD), 4-wave tiles two or more.
 void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
     constexpr int NWN = BN / WN;
     constexpr int NT = (BM / WM) * NWN * 64;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = NT / 4;                    // rows per pass: 4 x 16-B chunks per 64-B row
-    constexpr int A_SLOTS = BM / RPP, B_SLOTS = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+    constexpr int A_SLOTS = (BM + RPP - 1) / RPP, B_SLOTS = (BN + RPP - 1) / RPP;
+    static_assert(RPP % 16 == 0, "swizzle needs rows-per-pass % 16 == 0");
+    // a pass that runs past the panel (BM or BN not a multiple of RPP) is predicated per 16-row wave
+    // slice: its loads are issued out of range (the vmcnt count per stage stays constant) and its LDS
+    // writes are skipped
     constexpr int PANEL_A = BM * 64, PANEL_B = BN * 64;        // bytes
     constexpr int STAGE = 2 * PANEL_A + 2 * PANEL_B;
 
@@ -91,7 +113,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
         const int m = bm * BM + row0 + i * RPP;
-        if (m < M) {
+        if (m < M && row0 + i * RPP < BM) {
             const int hw = a.Ho * a.Wo;
             const int b = m / hw, r = m - b * hw;
             const int oy = r / a.Wo, ox = r - oy * a.Wo;
@@ -105,7 +127,8 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // ---- B: per-slot row offset in the weight planes
     unsigned wbase[B_SLOTS];
 #pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) wbase[i] = (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u;
+    for (int i = 0; i < B_SLOTS; ++i)
+        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u : OOB;
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
@@ -117,24 +140,46 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 
     StageRegs<A_SLOTS, B_SLOTS> S0, S1;
     auto gload = [&](StageRegs<A_SLOTS, B_SLOTS>& S) {
+        // chunks past the end of K (issued unconditionally to keep the loop branch-free, so that the
+        // compiler's vmcnt bookkeeping stays exact) read out of range -> zeros
+        const bool live = ld_kc < nk;
         const unsigned tap_off = (unsigned)(ld_ky * a.Wi + ld_kx) * PS + (unsigned)ld_c0 * 2u;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
-            const bool ok = (unsigned)(iy0[i] + ld_ky) < (unsigned)a.Hi && (unsigned)(ix0[i] + ld_kx) < (unsigned)a.Wi;
+            const bool ok = live && (unsigned)(iy0[i] + ld_ky) < (unsigned)a.Hi && (unsigned)(ix0[i] + ld_kx) < (unsigned)a.Wi;
             const unsigned vo = ok ? pbase[i] + tap_off : OOB;
-            S.ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo, 0, 0);
-            S.al[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo, lo_plane, 0);
+            S.ah[i] = asm_buffer_load_b128(rs_a, vo, 0u);
+            S.al[i] = asm_buffer_load_b128(rs_a, vo, lo_plane);
         }
         const unsigned koff = (unsigned)ld_kc * (HBK * 2);
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
-            S.bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, wbase[i], koff, 0);
-            S.bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, wbase[i], koff, 0);
+            const unsigned wo = live ? wbase[i] : OOB;
+            S.bh[i] = asm_buffer_load_b128(rs_wh, wo, koff);
+            S.bl[i] = asm_buffer_load_b128(rs_wl, wo, koff);
         }
         // advance the cursor (scalar)
         ++ld_kc;
         ld_c0 += HBK;
         if (ld_c0 >= a.Cin) { ld_c0 = 0; if (++ld_kx == a.kw) { ld_kx = 0; ++ld_ky; } }
+    };
+    constexpr int LOADS_PER_STAGE = 2 * A_SLOTS + 2 * B_SLOTS;
+    // wait until at most `LOADS_PER_STAGE` loads (the younger stage set) are outstanding: the older set S
+    // has landed.  Every register of S is an in/out operand so no use can be scheduled above the wait.
+    auto wait_stage = [&](StageRegs<A_SLOTS, B_SLOTS>& S) {
+        static_assert(A_SLOTS >= 1 && A_SLOTS <= 2 && B_SLOTS >= 1 && B_SLOTS <= 2, "stage shape");
+        if constexpr (A_SLOTS == 2 && B_SLOTS == 2)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.ah[0]), "+v"(S.al[0]), "+v"(S.ah[1]), "+v"(S.al[1]),
+                         "+v"(S.bh[0]), "+v"(S.bl[0]), "+v"(S.bh[1]), "+v"(S.bl[1]) :: "memory");
+        else if constexpr (A_SLOTS == 2 && B_SLOTS == 1)
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(S.ah[0]), "+v"(S.al[0]), "+v"(S.ah[1]), "+v"(S.al[1]),
+                         "+v"(S.bh[0]), "+v"(S.bl[0]) :: "memory");
+        else if constexpr (A_SLOTS == 1 && B_SLOTS == 2)
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(S.ah[0]), "+v"(S.al[0]),
+                         "+v"(S.bh[0]), "+v"(S.bl[0]), "+v"(S.bh[1]), "+v"(S.bl[1]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.ah[0]), "+v"(S.al[0]), "+v"(S.bh[0]), "+v"(S.bl[0]) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     // LDS image: panel row r, 16-B chunk c at byte r*64 + ((c ^ ((r>>2)&3)) << 4)
     const int wr_swz = (c16 ^ ((row0 >> 2) & 3)) << 4;           // RPP % 16 == 0 -> same swizzle for every slot
@@ -143,14 +188,18 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int o = (row0 + i * RPP) * 64 + wr_swz;
-            *reinterpret_cast<u32x4*>(st + o) = S.ah[i];
-            *reinterpret_cast<u32x4*>(st + PANEL_A + o) = S.al[i];
+            if ((i + 1) * RPP <= BM || row0 + i * RPP < BM) {
+                *reinterpret_cast<u32x4*>(st + o) = S.ah[i];
+                *reinterpret_cast<u32x4*>(st + PANEL_A + o) = S.al[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const int o = (row0 + i * RPP) * 64 + wr_swz;
-            *reinterpret_cast<u32x4*>(st + 2 * PANEL_A + o) = S.bh[i];
-            *reinterpret_cast<u32x4*>(st + 2 * PANEL_A + PANEL_B + o) = S.bl[i];
+            if ((i + 1) * RPP <= BN || row0 + i * RPP < BN) {
+                *reinterpret_cast<u32x4*>(st + 2 * PANEL_A + o) = S.bh[i];
+                *reinterpret_cast<u32x4*>(st + 2 * PANEL_A + PANEL_B + o) = S.bl[i];
+            }
         }
     };
 
@@ -168,106 +217,167 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     const int rd_swz = (lr >> 2) & 3;
     const int a_row = (wm * WM + lr) * 64, b_row = (wn * WN + lr) * 64;
 
-    auto compute = [&](int buf) {
+    // fragments of one whole K-chunk (both k16 steps) are read into registers first, then the next
+    // chunk's LDS writes and the global loads of the chunk after are issued, and only then the 24-MFMA
+    // block runs: the LDS write drain (~80 B/clk/CU through the VGPR path) and the load latency overlap
+    // with the matrix pipe instead of sitting between the MFMAs and the barrier.
+    struct Frags { f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN]; };
+    auto read_frags = [&](int buf, Frags& F) {
         const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             const int co = ((ks * 2 + lh) ^ rd_swz) << 4;
-            f16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                fah[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 64 + co);
-                fal[i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + a_row + i * 32 * 64 + co);
+                F.ah[ks][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 64 + co);
+                F.al[ks][i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + a_row + i * 32 * 64 + co);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                fbh[j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + b_row + j * 32 * 64 + co);
-                fbl[j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + PANEL_B + b_row + j * 32 * 64 + co);
+                F.bh[ks][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + b_row + j * 32 * 64 + co);
+                F.bl[ks][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + PANEL_B + b_row + j * 32 * 64 + co);
             }
+        }
+    };
+    auto mfma_block = [&](const Frags& F) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bl[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
                 }
-        }
     };
 
-    // prologue: chunks 0 and 1 in flight, chunk 0 staged
+    // prologue: chunks 0 and 1 in flight, chunk 0 staged, chunk 2 issued.  The steady state is
+    // branch-free: every half-iteration computes one chunk, stages the next and issues the load of the
+    // one after (chunks >= nk are zero chunks); an odd nk costs one zero chunk of MFMAs.
+    // vmcnt bookkeeping: loads complete in issue order; at every wait the older stage set has
+    // LOADS_PER_STAGE loads outstanding and the younger set LOADS_PER_STAGE more behind them.
     gload(S0);
-    if (nk > 1) gload(S1);
+    gload(S1);
+    wait_stage(S0);
     lds_write(S0, 0);
-    if (nk > 2) gload(S0);
+    gload(S0);
     __syncthreads();
+    Frags F;
     for (int t = 0; t < nk; t += 2) {
-        compute(0);                                   // chunk t
-        if (t + 1 < nk) {
-            lds_write(S1, 1);                         // chunk t+1 (waits only for S1's loads)
-            if (t + 3 < nk) gload(S1);                // chunk t+3
-        }
+        read_frags(0, F);                             // chunk t
+        wait_stage(S1);
+        lds_write(S1, 1);                             // chunk t+1
+        gload(S1);                                    // chunk t+3
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(F);
         __syncthreads();
-        if (t + 1 >= nk) break;
-        compute(1);                                   // chunk t+1
-        if (t + 2 < nk) {
-            lds_write(S0, 0);                         // chunk t+2
-            if (t + 4 < nk) gload(S0);                // chunk t+4
-        }
+        read_frags(1, F);                             // chunk t+1
+        wait_stage(S0);
+        lds_write(S0, 0);                             // chunk t+2
+        gload(S0);                                    // chunk t+4
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(F);
         __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
 
-    // ---- epilogue: D col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
+    if (a.dbg & 4) return;                            // timing experiment: no epilogue
+    // ---- epilogue.  The accumulators (MFMA layout: channel on the lane, 16 pixel rows per register set)
+    // are scaled / biased / activated and transposed through LDS (the stage buffers are dead: the main
+    // loop ended on a barrier) as an fp32 [rows][BN] tile, so that the residual loads and the output
+    // stores are row-contiguous 16-byte accesses (split format) or 256-byte row segments (decode).
+    constexpr int SMEM_BYTES = 2 * STAGE;
+    constexpr int RG_MAX = SMEM_BYTES / (BN * 4);
+    constexpr int RG = epi_row_group(BM, WM, RG_MAX);                     // rows per pass: multiple of WM dividing BM
+    static_assert(RG >= WM && BM % RG == 0, "epilogue row group");
+    float* T = reinterpret_cast<float*>(smem);
     const int hw = a.Ho * a.Wo;
+    const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
+#pragma unroll 1
+    for (int rg = 0; rg < BM; rg += RG) {
+        if (wm * WM >= rg && wm * WM < rg + RG) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = bn * BN + wn * WN + j * 32 + lr;
-        if (n >= a.Cout) continue;
-        if constexpr (EPI == EPI_DECODE) {
-            const float bias = a.bias[n], inv = a.inv_scale[n];
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WN + j * 32 + lr;
+                const int n = bn * BN + nl;
+                const float bias = (n < a.Cout ? a.bias[n] : 0.f) * escale;
+                const float inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = bm * BM + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m >= M) continue;
-                    float v = acc[i][j][e] * inv + bias;
-                    if (a.leaky) v = v > 0.f ? v : v * 0.1f;
-                    const int b = m / hw, cell = m - b * hw;
-                    const int gy = cell / a.dec.G, gx = cell - gy * a.dec.G;
-                    a.out[(int64_t)b * a.dec.img_stride + a.dec.head_off + (int64_t)cell * a.Cout + n] = h_decode(a.dec, v, n, gx, gy);
-                }
-        } else {
-            // everything in the SPLIT_SCALE domain: (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
-            const float bias = a.bias[n] * SPLIT_SCALE, inv = a.inv_scale[n] * SPLIT_SCALE;
-            _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + n;
-            const int64_t ops = 2 * a.out_ldc, olo = a.out_ldc;                 // halves per pixel, lo-plane offset
-            const _Float16* rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + n;
-            const int64_t rps = 2 * a.res_ldc, rlo = a.res_ldc;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                float r[16];
-                if constexpr (EPI == EPI_SPLIT_RES) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {                                // all residual loads first, one wait
-                        const int m = bm * BM + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const int64_t mm = m < M ? m : 0;
-                        r[e] = (float)rh[mm * rps] + (float)rh[mm * rps + rlo];
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = wm * WM - rg + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        float v = acc[i][j][e] * inv + bias;
+                        if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+                        T[rl * BN + nl] = v;
                     }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = bm * BM + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m >= M) continue;
-                    float v = acc[i][j][e] * inv + bias;
-                    if (a.leaky) v = v > 0.f ? v : v * 0.1f;
-                    if constexpr (EPI == EPI_SPLIT_RES) v += r[e];
-                    const _Float16 h = (_Float16)v;
-                    oh[(int64_t)m * ops] = h;
-                    oh[(int64_t)m * ops + olo] = (_Float16)(v - (float)h);
-                }
             }
         }
+        __syncthreads();
+        if constexpr (EPI == EPI_DECODE) {
+            // thread <-> fixed channel n: anchor / attribute kind are per-thread constants; rows advance by NT/BN
+            constexpr int RSTEP = NT / BN > 0 ? NT / BN : 1;
+            static_assert(NT % BN == 0 || BN % NT == 0, "decode mapping");
+            for (int nl = tid % BN; nl < BN; nl += NT) {
+                const int n = bn * BN + nl;
+                if (n >= a.Cout) continue;
+                const int an = n / a.dec.attrs, c = n - an * a.dec.attrs;
+                const bool is_wh = (c == 2 || c == 3) && !a.dec.train;
+                const bool is_raw = (c == 2 || c == 3) && a.dec.train;
+                const float anc = (c == 2 ? a.dec.aw[an] : a.dec.ah[an]);
+                const int r0 = (NT >= BN) ? tid / BN : 0;
+                int m = bm * BM + rg + r0;
+                int b = m / hw, cell = m - b * hw;
+                int gy = cell / a.dec.G, gx = cell - gy * a.dec.G;
+                for (int r = r0; r < RG && m < M; r += RSTEP, m += RSTEP) {
+                    const float v = T[r * BN + nl];
+                    float o;
+                    if (is_raw) o = v;
+                    else {
+                        const float ex = expf(is_wh ? v : -v);            // one exp serves both kinds
+                        if (is_wh) o = (ex * anc) * a.dec.stride;
+                        else {
+                            o = 1.0f / (1.0f + ex);
+                            if (c < 2 && !a.dec.train) o = (o + (float)(c == 0 ? gx : gy)) * a.dec.stride;
+                        }
+                    }
+                    a.out[(int64_t)b * a.dec.img_stride + a.dec.head_off + (int64_t)(gy * a.dec.G + gx) * a.Cout + n] = o;
+                    gx += RSTEP;
+                    while (gx >= a.dec.G) { gx -= a.dec.G; if (++gy >= a.dec.G) { gy = 0; ++b; } }
+                }
+            }
+        } else {
+            constexpr int GPR = BN / 8;                                   // 8-channel (16-byte) groups per row
+            _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
+            const _Float16* rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+            for (int g = tid; g < RG * GPR; g += NT) {
+                const int r = g / GPR, c8 = (g - r * GPR) * 8;
+                const int m = bm * BM + rg + r;
+                if (m >= M || bn * BN + c8 >= a.Cout) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + c8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if constexpr (EPI == EPI_SPLIT_RES) {
+                    const _Float16* q = rh + (int64_t)m * 2 * a.res_ldc + c8;
+                    const f16x8 qh = *reinterpret_cast<const f16x8*>(q);
+                    const f16x8 ql = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
+                }
+                f16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 h = (_Float16)v[e];
+                    ph[e] = h;
+                    pl[e] = (_Float16)(v[e] - (float)h);
+                }
+                _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
+                *reinterpret_cast<f16x8*>(q) = ph;
+                *reinterpret_cast<f16x8*>(q + a.out_ldc) = pl;
+            }
+        }
+        if (rg + RG < BM) __syncthreads();
     }
 }
 
@@ -276,6 +386,8 @@ static const ConvVariantInfo kHVariants[HV_COUNT] = {
     {128, 64, "conv_igemm_f16s3<128x64,w64x32>"},
     {64, 64, "conv_igemm_f16s3<64x64,w32x32>"},
     {64, 128, "conv_igemm_f16s3<64x128,w32x64>"},
+    {256, 128, "conv_igemm_f16s3<256x128,w64x64>"},
+    {128, 256, "conv_igemm_f16s3<128x256,w64x64>"},
 };
 
 const ConvVariantInfo& conv_f16s3_variant_info(int v) { return kHVariants[v < 0 || v >= HV_COUNT ? 0 : v]; }
@@ -294,7 +406,8 @@ static int launch_h(const ConvArgs& a, hipStream_t s) {
     return hip_fail(hipGetLastError(), "conv_igemm_f16s3 launch");
 }
 
-int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s) {
+int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
+    ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_f16s3: null pointer"); return RTOD_E_ARG; }
     if (a.Cin % HBK || a.in_ldc % 8 || a.in_coff % 8 || a.Kpad % HBK || a.K != a.Kpad || a.K != a.kh * a.kw * a.Cin) {
         set_error("launch_conv_f16s3: needs Cin %% 32 == 0 and 8-channel aligned views (Cin=%d ldc=%ld coff=%d K=%d Kpad=%d)", a.Cin, (long)a.in_ldc, a.in_coff, a.K, a.Kpad);
@@ -306,11 +419,18 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s) {
         set_error("launch_conv_f16s3: buffer of %u / %u bytes outside (0, 2 GiB)", a.in_bytes, a.w_bytes); return RTOD_E_ARG;
     }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_f16s3: input view exceeds its buffer"); return RTOD_E_ARG; }
+    // timing-only experiments (cdna guide 7: zero-record descriptors drop the loads of one operand, results are garbage)
+    static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;
+    if (dbg_zero & 1) a.in_bytes = 1;
+    if (dbg_zero & 2) a.w_bytes = 1;
+    a.dbg = dbg_zero;
     switch (variant) {
         case HV_128x128: return launch_h<128, 128, 64, 64>(a, s);
         case HV_128x64: return launch_h<128, 64, 64, 32>(a, s);
         case HV_64x64: return launch_h<64, 64, 32, 32>(a, s);
         case HV_64x128: return launch_h<64, 128, 32, 64>(a, s);
+        case HV_256x128: return launch_h<256, 128, 64, 64>(a, s);
+        case HV_128x256: return launch_h<128, 256, 64, 64>(a, s);
     }
     set_error("launch_conv_f16s3: unknown variant %d", variant);
     return RTOD_E_ARG;

@@ -623,41 +623,10 @@ int Plan::choose_variant(const Layer& L, int batch) const {
     return big >= 512 ? CV_128x128 : CV_64x64;     // keep >= 2 workgroups per CU in flight
 }
 
-int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
-    const char* force = getenv("RTOD_F16S3_VARIANT");
-    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < HV_COUNT) return v; }
-    if (L.cout <= 64) return HV_128x64;
-    const int64_t M = (int64_t)batch * L.hout * L.wout;
-    const int64_t gn = (L.cout + 127) / 128;
-    if (((M + 127) / 128) * gn >= 512) return HV_128x128;
-    if (((M + 63) / 64) * gn >= 512) return HV_64x128;
-    return HV_64x64;
-}
-
-int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms) {
-    if (!weights_loaded) { set_error("forward: load_weights has not been called"); return RTOD_E_STATE; }
-    if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
-    if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
-    RTOD_HIP(hipSetDevice(device));
-    const size_t nl = launches.size();
-    if (launch_ms && events.size() < 2 * nl) {
-        while (events.size() < 2 * nl) { hipEvent_t e; RTOD_HIP(hipEventCreate(&e)); events.push_back(e); }
-    }
-    for (size_t li = 0; li < nl; ++li) {
-        const Launch& l = launches[li];
-        if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li], s));
-        int rc = RTOD_OK;
-        switch (l.kind) {
-            case LK_PACK: {
-                View v = view_of(-1);
-                rc = launch_pack_input(x, batch, 3, height, width, v.base, 4, s);
-                break;
-            }
-            case LK_CONV: {
+int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const {
                 const Layer& L = layers[l.layer];
                 const PackedConv& pc = convs[l.conv_slot];
                 const View in = view_of(l.in_layer);
-                ConvArgs a;
                 a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
                 a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
                 a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
@@ -682,7 +651,106 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                     if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
                     a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
                 }
-                rc = pc.split ? launch_conv_f16s3(a, choose_variant_f16s3(L, batch), s) : launch_conv(a, choose_variant(L, batch), s);
+    return RTOD_OK;
+}
+
+// Autotune: for every distinct conv shape of this batch size, time each split-f16 tile variant on the
+// device (3 timed launches after 1 warm-up, HIP events on `s`) and remember the fastest.  Tile choice
+// interacts with the 256-CU round structure (a 722-block grid on 512 resident slots runs two rounds at
+// 70 % efficiency) in ways a closed-form heuristic keeps getting wrong; measuring takes ~0.2 s once.
+int Plan::autotune(int batch, float* out, hipStream_t s) {
+    if (precision != 1) return RTOD_OK;
+    if (tuned.count(batch)) return RTOD_OK;
+    std::vector<int> best(launches.size(), -1);
+    if (getenv("RTOD_NO_AUTOTUNE")) { tuned[batch] = best; return RTOD_OK; }
+    std::map<std::vector<int>, int> cache;
+    hipEvent_t e0, e1;
+    RTOD_HIP(hipEventCreate(&e0)); RTOD_HIP(hipEventCreate(&e1));
+    int rc = RTOD_OK;
+    for (size_t li = 0; li < launches.size() && !rc; ++li) {
+        const Launch& l = launches[li];
+        if (l.kind != LK_CONV || !convs[l.conv_slot].split) continue;
+        const Layer& L = layers[l.layer];
+        const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2};
+        auto it = cache.find(key);
+        if (it != cache.end()) { best[li] = it->second; continue; }
+        ConvArgs a;
+        rc = build_conv_args(l, batch, out, a);
+        if (rc) break;
+        float best_ms = 1e30f; int best_v = choose_variant_f16s3(L, batch);
+        for (int v = 0; v < HV_COUNT && !rc; ++v) {
+            const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
+            if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
+            rc = launch_conv_f16s3(a, v, s);                                          // warm-up
+            if (rc) break;
+            hipEventRecord(e0, s);
+            for (int r = 0; r < 3 && !rc; ++r) rc = launch_conv_f16s3(a, v, s);
+            hipEventRecord(e1, s);
+            if (rc) break;
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "autotune sync"); break; }
+            float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best_ms) { best_ms = ms; best_v = v; }
+        }
+        best[li] = best_v;
+        cache[key] = best_v;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    tuned[batch] = best;
+    return RTOD_OK;
+}
+
+int Plan::variant_for(const Launch& l, int batch) const {
+    const char* force = getenv("RTOD_F16S3_VARIANT");
+    if (!(force && *force)) {
+        auto it = tuned.find(batch);
+        const size_t idx = &l - &launches[0];
+        if (it != tuned.end() && idx < it->second.size() && it->second[idx] >= 0) return it->second[idx];
+    }
+    return choose_variant_f16s3(layers[l.layer], batch);
+}
+
+int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
+    const char* force = getenv("RTOD_F16S3_VARIANT");
+    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < HV_COUNT) return v; }
+    if (L.cout <= 64) return HV_128x64;
+    const int64_t M = (int64_t)batch * L.hout * L.wout;
+    const int64_t gn = (L.cout + 127) / 128;
+    if (((M + 127) / 128) * gn >= 512) return HV_128x128;
+    if (((M + 63) / 64) * gn >= 512) return HV_64x128;
+    return HV_64x64;
+}
+
+int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms) {
+    if (!weights_loaded) { set_error("forward: load_weights has not been called"); return RTOD_E_STATE; }
+    if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
+    if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
+    RTOD_HIP(hipSetDevice(device));
+    {
+        const int rc0 = autotune(batch, out, s);       // first forward of a batch size only (synchronises once)
+        if (rc0) return rc0;
+    }
+    const size_t nl = launches.size();
+    if (launch_ms && events.size() < 2 * nl) {
+        while (events.size() < 2 * nl) { hipEvent_t e; RTOD_HIP(hipEventCreate(&e)); events.push_back(e); }
+    }
+    for (size_t li = 0; li < nl; ++li) {
+        const Launch& l = launches[li];
+        if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li], s));
+        int rc = RTOD_OK;
+        switch (l.kind) {
+            case LK_PACK: {
+                View v = view_of(-1);
+                rc = launch_pack_input(x, batch, 3, height, width, v.base, 4, s);
+                break;
+            }
+            case LK_CONV: {
+                const Layer& L = layers[l.layer];
+                const PackedConv& pc = convs[l.conv_slot];
+                ConvArgs a;
+                rc = build_conv_args(l, batch, out, a);
+                if (rc) return rc;
+                rc = pc.split ? launch_conv_f16s3(a, variant_for(l, batch), s) : launch_conv(a, choose_variant(L, batch), s);
                 break;
             }
             case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;
@@ -723,7 +791,7 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
     const int64_t in_b = (int64_t)L.hin * L.win * L.cin * 4, out_b = (int64_t)L.hout * L.wout * L.cout * 4;
     switch (l.kind) {
         case LK_CONV:
-            o->variant = convs[l.conv_slot].split ? 100 + choose_variant_f16s3(L, batch) : choose_variant(L, batch);
+            o->variant = convs[l.conv_slot].split ? 100 + variant_for(l, batch) : choose_variant(L, batch);
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
             o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
             o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);

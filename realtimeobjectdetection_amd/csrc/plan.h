@@ -89,6 +89,10 @@ struct Plan {
     View view_of(int layer) const;            // resolves aliases; base == nullptr if not materialised
     int choose_variant(const Layer& L, int batch) const;
     int choose_variant_f16s3(const Layer& L, int batch) const;
+    int build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const;
+    int autotune(int batch, float* out, hipStream_t s);
+    int variant_for(const Launch& l, int batch) const;
+    std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)
     std::string describe() const;
     void fill_launch_info(int idx, rtod_launch_info* o, int batch) const;
 };

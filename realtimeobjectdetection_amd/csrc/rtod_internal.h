@@ -60,6 +60,7 @@ struct ConvArgs {
     const _Float16* w_lo = nullptr;
     const float* inv_scale = nullptr;           // [Npad]: 1 / (2^e_n * SPLIT_SCALE)
     unsigned in_bytes = 0, w_bytes = 0;         // extents of the input buffer / one weight plane (buffer-load range check)
+    int dbg = 0;                                // timing experiments only (RTOD_DBG_ZERO)
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
 };
 
@@ -71,7 +72,7 @@ enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, C
 struct ConvVariantInfo { int bm, bn; const char* name; };
 const ConvVariantInfo& conv_variant_info(int v);
 int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
-enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_COUNT };
+enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_256x128 = 4, HV_128x256 = 5, HV_COUNT };
 const ConvVariantInfo& conv_f16s3_variant_info(int v);
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 
