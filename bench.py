@@ -95,6 +95,16 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=25.0):
                       % (iters, res, res, batch, torch.__version__, cores)}
 
 
+def rocprof_kernel_name(tile_name, epi):
+    """'conv_igemm_f16s3<128x128,w64x64>' + epilogue id -> the demangled name rocprofv3 prints."""
+    import re
+    m = re.match(r"conv_igemm_(f16s3|f32)<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
+    kind, bm, bn, wm, wn = m.group(1), *[int(v) for v in m.groups()[1:]]
+    if kind == "f16s3":
+        return "void rtod::conv_igemm_f16s3_kernel<%d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, wm, wn, epi)
+    return "void rtod::conv_igemm_f32_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, wm, wn)
+
+
 def roofline_from_launches(model, x, steps):
     """Instrumented replay: hipEvent pair around every launch; group conv launches by tile variant."""
     import ctypes as C
@@ -111,9 +121,11 @@ def roofline_from_launches(model, x, steps):
     for li, ms in zip(infos, tot):
         if li.kind != 0:
             continue
-        # the variant actually launched depends on the batch: recompute as the plan does
+        # group by the exact kernel instantiation rocprofv3 reports (tile variant + epilogue)
         name = lib.rtod_conv_variant_name(li.variant).decode()
-        g = groups.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        epi = 2 if li.fused_decode else (1 if li.fused_residual else 0)
+        kname = rocprof_kernel_name(name, epi)
+        g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "tile": name})
         g["ms"] += float(ms); g["flops"] += float(li.flops_per_frame) * B; g["launches"] += 1
     dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
     name, g = dom
@@ -212,12 +224,12 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof, per_layer, groups = roofline_from_launches(model, x, max(1, min(args.steps, 10)))
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/traffic.json,
+        # written by tools/summarize_profiles.py: 2*FETCH_SIZE + WRITE_SIZE); null if it was not profiled
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_path):
+        if os.path.exists(tr_path) and R == 608 and B == 8:
             try:
-                tr = json.load(open(tr_path))
-                if tr.get("kernel") == roof["kernel"] and tr.get("res") == R and tr.get("batch") == B:
-                    roof["traffic"] = tr.get("hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tr_path)).get(roof["kernel"])
             except Exception:
                 pass
         if args.layers_out:
