@@ -52,7 +52,7 @@ typedef struct rtod_plan_info {
 
 typedef struct rtod_launch_info {
     int32_t layer;             /* cfg layer index this launch implements (fused layers: the conv) */
-    int32_t kind;              /* 0 conv-igemm, 1 input-pack, 2 upsample, 3 add, 4 maxpool, 5 decode, 6 copy */
+    int32_t kind;              /* 0 conv-igemm, 1 input-pack, 2 upsample, 3 add, 4 maxpool, 5 decode, 6 copy, 7 stem conv */
     int32_t variant;           /* conv tile variant id (see rtod_conv_variant_name) */
     int32_t ksize, stride, cin, cout, hout, wout;
     int32_t fused_residual, fused_decode;

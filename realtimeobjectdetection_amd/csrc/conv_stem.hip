@@ -1,0 +1,123 @@
+// Stem convolution (first layer: 3x3, Cin = 3, pad 1) on the exact-fp32 MFMA, reading the network input
+// directly in the reference's NCHW layout (src/darknet.py:199: x is [B,3,H,W]) and writing NHWC in either
+// activation format.  Replaces the pack_input + generic implicit-GEMM pair: K = 27 is too small for 32-wide
+// K-chunks (the generic kernel pads it to 64), and the layer is HBM-write bound (608x608x32 outputs per frame).
+//
+// One wave = 32 output pixels x 32 output channels = one 32x32 MFMA tile; K = 27 (+1 zero) = 14 steps of
+// v_mfma_f32_32x32x2_f32.  A operand: lane l -> pixel l&31, k = 2s + (l>>5), gathered straight from the three
+// input planes (32 consecutive pixels per half-wave: coalesced 128-byte rows); B operand: 14 registers of
+// BN-folded weights held for the whole kernel.  The tile is transposed through LDS so each lane stores eight
+// consecutive channels (16 bytes per plane).  Numerics: exact fp32 fmaf chains (both precisions keep the stem exact).
+#include "rtod_internal.h"
+
+namespace rtod {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+
+struct StemArgs {
+    const float* x;          // [B,3,H,W]
+    const float* w;          // [28][Cout] (k-major, k = (ky*3+kx)*3 + c, row 27 = 0), BN folded
+    const float* bias;       // [Cout]
+    float* out; int64_t out_ldc; int out_coff; int out_split;
+    int B, H, W, Ho, Wo, stride, Cout, leaky;
+};
+
+__global__ __launch_bounds__(256)
+void conv_stem_kernel(const StemArgs a) {
+    __shared__ __attribute__((aligned(16))) float T[4][32 * 36];       // per wave: 32 pixels x (32+4) floats
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int M = a.B * a.Ho * a.Wo;
+    const int n_ct = a.Cout / 32;
+    const int64_t plane = (int64_t)a.H * a.W;
+    float* Tw = T[wave];
+
+    for (int ct = 0; ct < n_ct; ++ct) {
+        float wreg[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) wreg[s] = a.w[(2 * s + lh) * a.Cout + ct * 32 + lr];
+        const float bias = a.bias[ct * 32 + lr];
+        for (int tile = blockIdx.x * 4 + wave; tile * 32 < M; tile += gridDim.x * 4) {
+            const int m = tile * 32 + lr;
+            const bool mok = m < M;
+            const int mm = mok ? m : 0;
+            const int hw = a.Ho * a.Wo;
+            const int b = mm / hw, r = mm - b * hw;
+            const int oy = r / a.Wo, ox = r - oy * a.Wo;
+            const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
+            const float* xb = a.x + (int64_t)b * 3 * plane;
+            float av[14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                const int k = 2 * s + lh;                       // 0..27
+                const int tap = k / 3, c = k - tap * 3;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                const bool ok = mok && k < 27 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                av[s] = ok ? xb[c * plane + (int64_t)iy * a.W + ix] : 0.f;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wreg[s], acc, 0, 0, 0);
+            // D: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[e] + bias;
+                if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+                Tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + lr] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the wave's own LDS writes, then reads (in order)
+            __builtin_amdgcn_wave_barrier();
+            // 32 pixels x 4 groups of 8 channels = 128 groups, two per lane
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = lane + q * 64;
+                const int p = g >> 2, c8 = (g & 3) * 8;
+                const int mo = tile * 32 + p;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8 + 4);
+                if (mo < M) {
+                    if (a.out_split) {
+                        f16x8s ph, pl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = (e < 4 ? v0[e] : v1[e - 4]) * SPLIT_SCALE;
+                            const _Float16 h = (_Float16)v;
+                            ph[e] = h; pl[e] = (_Float16)(v - (float)h);
+                        }
+                        _Float16* o = reinterpret_cast<_Float16*>(a.out) + (int64_t)mo * 2 * a.out_ldc + a.out_coff + ct * 32 + c8;
+                        *reinterpret_cast<f16x8s*>(o) = ph;
+                        *reinterpret_cast<f16x8s*>(o + a.out_ldc) = pl;
+                    } else {
+                        float* o = a.out + (int64_t)mo * a.out_ldc + a.out_coff + ct * 32 + c8;
+                        *reinterpret_cast<f32x4*>(o) = v0;
+                        *reinterpret_cast<f32x4*>(o + 4) = v1;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+int launch_conv_stem(const float* x, const float* w, const float* bias, const View& out, int B, int H, int W,
+                     int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s) {
+    if (!x || !w || !bias || !out.base) { set_error("conv_stem: null pointer"); return RTOD_E_ARG; }
+    if (Cout % 32 || Cout < 32 || out.C != Cout || out.H != Ho || out.W != Wo || out.ldc % 8 || out.coff % 8) { set_error("conv_stem: bad output view"); return RTOD_E_ARG; }
+    if ((int64_t)B * Ho * Wo >= (1ll << 31)) { set_error("conv_stem: pixel count exceeds int32"); return RTOD_E_ARG; }
+    StemArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.out = out.base; a.out_ldc = out.ldc; a.out_coff = out.coff; a.out_split = out.split;
+    a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.Cout = Cout; a.leaky = leaky;
+    const int64_t tiles = ((int64_t)B * Ho * Wo + 31) / 32;
+    int grid = (int)((tiles + 3) / 4);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(grid), dim3(256), 0, s, a);
+    return hip_fail(hipGetLastError(), "conv_stem launch");
+}
+
+}  // namespace rtod

@@ -341,8 +341,11 @@ int Plan::plan_buffers() {
     // launch list
     launches.clear();
     convs.clear();
-    { Launch l; l.kind = LK_PACK; l.layer = 0; launches.push_back(l); }
     if (layers[0].type != LT_CONV) { set_error("cfg: first layer must be convolutional"); return RTOD_E_CFG; }
+    // dedicated stem kernel (reads NCHW directly) when layer 0 is a plain 3x3 / pad 1 conv with 32 or 64 filters
+    const bool use_stem = layers[0].size == 3 && layers[0].pad == 1 && layers[0].cin == 3 && layers[0].cout % 32 == 0 &&
+                          layers[0].cout <= 64 && layers[0].fused_into < 0 && !getenv("RTOD_NO_STEM");
+    if (!use_stem) { Launch l; l.kind = LK_PACK; l.layer = 0; launches.push_back(l); }
     for (auto& L : layers) {
         const int i = L.index;
         Launch l; l.layer = i;
@@ -366,6 +369,7 @@ int Plan::plan_buffers() {
                     }
                 }
                 PackedConv pc; pc.layer = i; pc.cin_p = (i == 0) ? 4 : L.cin;
+                if (i == 0 && use_stem) { pc.stem = true; l.kind = LK_STEM; }
                 if (pc.cin_p % 4) { set_error("layer %d: %d input channels not a multiple of 4", i, pc.cin_p); return RTOD_E_CFG; }
                 pc.K = L.size * L.size * pc.cin_p; pc.Kpad = (pc.K + 31) / 32 * 32; pc.Npad = (L.cout + 127) / 128 * 128;
                 l.conv_slot = (int)convs.size();
@@ -406,6 +410,7 @@ int Plan::plan_buffers() {
     for (const auto& l : launches) {
         const int t = l.layer;
         if (l.kind == LK_PACK) { touch(input_buf, 0); continue; }
+        if (l.kind == LK_STEM) { touch(buf_of_layer(l.out_layer), t); continue; }
         touch(buf_of_layer(l.in_layer), t);
         if (l.in2_layer >= 0) touch(buf_of_layer(l.in2_layer), t);
         if (l.kind == LK_COPY) touch(l.out_buf, t);
@@ -422,7 +427,7 @@ int Plan::plan_buffers() {
 }
 
 bool Plan::uses_split(const Layer& L, int cin_p) const {
-    return precision == 1 && L.index > 0;      // the stem stays on the exact-fp32 kernel and writes the split format
+    return precision == 1 && L.index > 0;      // layer 0 stays on an exact-fp32 kernel and writes the split format
 }
 
 int Plan::check_split_supported() const {
@@ -452,7 +457,9 @@ void Plan::layout_weights() {
         const Layer& L = layers[pc.layer];
         pc.split = uses_split(L, pc.cin_p);
         const int64_t panel = (int64_t)pc.Npad * pc.Kpad;
-        if (pc.split) {
+        if (pc.stem) {
+            pc.w_off = packed_floats; packed_floats += 28 * (int64_t)L.cout;
+        } else if (pc.split) {
             pc.w_off = packed_floats; packed_floats += panel / 2;       // f16 hi plane
             pc.wl_off = packed_floats; packed_floats += panel / 2;      // f16 lo plane
             pc.s_off = packed_floats; packed_floats += pc.Npad;
@@ -563,7 +570,16 @@ int Plan::load_weights(const float* w, size_t n) {
             for (int o = 0; o < C; ++o) bias[o] = p[o];
             p += C;
         }
-        if (!pc.split) {
+        if (pc.stem) {
+            float* wp = packed.data() + pc.w_off;                 // [28][Cout], k = (ky*3+kx)*3 + c
+            for (int o = 0; o < C; ++o)
+                for (int c = 0; c < cin; ++c)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const float v = p[(((int64_t)o * cin + c) * k + ky) * k + kx];
+                            wp[(int64_t)((ky * k + kx) * 3 + c) * C + o] = (float)((double)v * scale[o]);
+                        }
+        } else if (!pc.split) {
             float* wp = packed.data() + pc.w_off;
             for (int o = 0; o < C; ++o)
                 for (int c = 0; c < cin; ++c)
@@ -683,12 +699,12 @@ int Plan::autotune(int batch, float* out, hipStream_t s) {
             if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
             rc = launch_conv_f16s3(a, v, s);                                          // warm-up
             if (rc) break;
-            hipEventRecord(e0, s);
+            (void)hipEventRecord(e0, s);
             for (int r = 0; r < 3 && !rc; ++r) rc = launch_conv_f16s3(a, v, s);
-            hipEventRecord(e1, s);
+            (void)hipEventRecord(e1, s);
             if (rc) break;
             if (hipEventSynchronize(e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "autotune sync"); break; }
-            float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
             if (ms < best_ms) { best_ms = ms; best_v = v; }
         }
         best[li] = best_v;
@@ -753,6 +769,14 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 rc = pc.split ? launch_conv_f16s3(a, variant_for(l, batch), s) : launch_conv(a, choose_variant(L, batch), s);
                 break;
             }
+            case LK_STEM: {
+                const Layer& L = layers[l.layer];
+                const PackedConv& pc = convs[l.conv_slot];
+                const View o = view_of(l.out_layer);
+                rc = launch_conv_stem(x, d_weights + pc.w_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
+                                      L.stride, L.cout, L.leaky ? 1 : 0, s);
+                break;
+            }
             case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;
             case LK_MAXPOOL: rc = launch_maxpool(view_of(l.in_layer), view_of(l.out_layer), batch, layers[l.layer].size, layers[l.layer].stride, s); break;
             case LK_ADD: rc = launch_add(view_of(l.in_layer), view_of(l.in2_layer), view_of(l.out_layer), batch, s); break;
@@ -790,6 +814,11 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
     o->ksize = L.size; o->stride = L.stride; o->cin = L.cin; o->cout = L.cout; o->hout = L.hout; o->wout = L.wout;
     const int64_t in_b = (int64_t)L.hin * L.win * L.cin * 4, out_b = (int64_t)L.hout * L.wout * L.cout * 4;
     switch (l.kind) {
+        case LK_STEM:
+            o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
+            o->bytes_per_frame = in_b + out_b;
+            o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
+            break;
         case LK_CONV:
             o->variant = convs[l.conv_slot].split ? 100 + variant_for(l, batch) : choose_variant(L, batch);
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;

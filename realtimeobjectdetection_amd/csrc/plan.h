@@ -36,7 +36,7 @@ struct Buffer {
     int64_t offset = 0;           // floats from arena base, for max_batch frames
 };
 
-enum LaunchKind { LK_CONV = 0, LK_PACK = 1, LK_UPSAMPLE = 2, LK_ADD = 3, LK_MAXPOOL = 4, LK_DECODE = 5, LK_COPY = 6 };
+enum LaunchKind { LK_CONV = 0, LK_PACK = 1, LK_UPSAMPLE = 2, LK_ADD = 3, LK_MAXPOOL = 4, LK_DECODE = 5, LK_COPY = 6, LK_STEM = 7 };
 
 struct Launch {
     int kind = LK_CONV;
@@ -53,6 +53,7 @@ struct PackedConv {
     int layer = 0;
     int cin_p = 0, K = 0, Kpad = 0, Npad = 0;
     int64_t w_off = 0, b_off = 0;     // float offsets into the device weight arena
+    bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32
     bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
 };

@@ -76,6 +76,8 @@ enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3
 const ConvVariantInfo& conv_f16s3_variant_info(int v);
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 
+int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
+                     int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
 int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s);

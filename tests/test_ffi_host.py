@@ -70,7 +70,7 @@ def test_native_plan_matches_python_ir(net, res):
     assert flops == ir.conv_flops
     assert 3 not in kinds and 5 not in kinds and 6 not in kinds        # no add / decode / copy launches
     n_conv = sum(1 for L in ir.layers if L.type == "convolutional")
-    assert kinds.count(0) == n_conv
+    assert kinds.count(0) + kinds.count(7) == n_conv            # 7 = dedicated stem conv
     _ffi.lib().rtod_plan_destroy(h)
 
 
