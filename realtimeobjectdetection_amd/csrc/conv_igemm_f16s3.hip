@@ -19,55 +19,14 @@
 // Main loop: BMxBNx32 per stage; LDS double-buffered, four 64-byte-row f16 panels per stage with a
 // 16-byte-chunk XOR swizzle (chunk ^= (row>>2)&3: conflict-free ds_read_b128 / ds_write_b128);
 // two register stage sets keep two K-chunks of global loads in flight; one barrier per K-chunk.
+// K order: k = ((c/32)*kh*kw + tap)*32 + c%32 (channel chunk outer, tap inner).
 // Addressing: the tap (ky,kx) and channel offset of a K-chunk are wave-uniform (Cin % 32 == 0) and
 // advanced in scalar registers; loads are raw buffer loads whose per-lane voffset is
 // pixel-origin + tap offset, forced out of range (-> zeros) for padding taps and rows >= M.
-#include "rtod_internal.h"
+#include "conv_f16s3_common.h"
 #include <cstdlib>
 
 namespace rtod {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int HBK = 32;                  // K elements per LDS stage (64 bytes per panel row)
-constexpr unsigned OOB = 0x80000000u;    // voffset beyond any buffer (< 2 GiB enforced on the host)
-
-enum { EPI_SPLIT = 0, EPI_SPLIT_RES = 1, EPI_DECODE = 2 };
-
-__device__ __forceinline__ float h_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-__device__ __forceinline__ float h_decode(const DecodeArgs& d, float v, int n, int gx, int gy) {
-    const int a = n / d.attrs;
-    const int c = n - a * d.attrs;
-    if (c >= 4) return h_sigmoid(v);
-    if (c < 2) {
-        float s = h_sigmoid(v);
-        if (d.train) return s;
-        return (s + (float)(c == 0 ? gx : gy)) * d.stride;
-    }
-    if (d.train) return v;
-    const float anc = (c == 2) ? d.aw[a] : d.ah[a];
-    return (expf(v) * anc) * d.stride;
-}
-
-// Raw buffer load issued through inline asm so that hipcc's s_waitcnt insertion does not see it: the
-// main loop keeps two K-chunks of loads in flight across barriers and waits with hand-counted
-// vmcnt(N) (cdna guide 5.7: loads hidden from the compiler need their own counted wait, and every
-// destination must be named by the wait statement before its first use).
-__device__ __forceinline__ u32x4 asm_buffer_load_b128(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
-    u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
-    return v;
-}
-
-constexpr int epi_row_group(int bm, int wm, int rg_max) {
-    int best = wm;
-    for (int r = wm; r <= bm && r <= rg_max; r += wm) if (bm % r == 0) best = r;
-    return best;
-}
 
 template <int ASL, int BSL>
 struct StageRegs {
@@ -158,10 +117,10 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             S.bh[i] = asm_buffer_load_b128(rs_wh, wo, koff);
             S.bl[i] = asm_buffer_load_b128(rs_wl, wo, koff);
         }
-        // advance the cursor (scalar)
+        // advance the cursor (scalar).  K order = (32-channel chunk outer, tap inner), the same order as the
+        // band kernel and the packed weights, so every tile variant / kernel sums each output identically
         ++ld_kc;
-        ld_c0 += HBK;
-        if (ld_c0 >= a.Cin) { ld_c0 = 0; if (++ld_kx == a.kw) { ld_kx = 0; ++ld_ky; } }
+        if (++ld_kx == a.kw) { ld_kx = 0; if (++ld_ky == a.kh) { ld_ky = 0; ld_c0 += HBK; } }
     };
     constexpr int LOADS_PER_STAGE = 2 * A_SLOTS + 2 * B_SLOTS;
     // wait until at most `LOADS_PER_STAGE` loads (the younger stage set) are outstanding: the older set S
@@ -283,102 +242,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
 
     if (a.dbg & 4) return;                            // timing experiment: no epilogue
-    // ---- epilogue.  The accumulators (MFMA layout: channel on the lane, 16 pixel rows per register set)
-    // are scaled / biased / activated and transposed through LDS (the stage buffers are dead: the main
-    // loop ended on a barrier) as an fp32 [rows][BN] tile, so that the residual loads and the output
-    // stores are row-contiguous 16-byte accesses (split format) or 256-byte row segments (decode).
-    constexpr int SMEM_BYTES = 2 * STAGE;
-    constexpr int RG_MAX = SMEM_BYTES / (BN * 4);
-    constexpr int RG = epi_row_group(BM, WM, RG_MAX);                     // rows per pass: multiple of WM dividing BM
-    static_assert(RG >= WM && BM % RG == 0, "epilogue row group");
-    float* T = reinterpret_cast<float*>(smem);
-    const int hw = a.Ho * a.Wo;
-    const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
-#pragma unroll 1
-    for (int rg = 0; rg < BM; rg += RG) {
-        if (wm * WM >= rg && wm * WM < rg + RG) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = wn * WN + j * 32 + lr;
-                const int n = bn * BN + nl;
-                const float bias = (n < a.Cout ? a.bias[n] : 0.f) * escale;
-                const float inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = wm * WM - rg + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        float v = acc[i][j][e] * inv + bias;
-                        if (a.leaky) v = v > 0.f ? v : v * 0.1f;
-                        T[rl * BN + nl] = v;
-                    }
-            }
-        }
-        __syncthreads();
-        if constexpr (EPI == EPI_DECODE) {
-            // thread <-> fixed channel n: anchor / attribute kind are per-thread constants; rows advance by NT/BN
-            constexpr int RSTEP = NT / BN > 0 ? NT / BN : 1;
-            static_assert(NT % BN == 0 || BN % NT == 0, "decode mapping");
-            for (int nl = tid % BN; nl < BN; nl += NT) {
-                const int n = bn * BN + nl;
-                if (n >= a.Cout) continue;
-                const int an = n / a.dec.attrs, c = n - an * a.dec.attrs;
-                const bool is_wh = (c == 2 || c == 3) && !a.dec.train;
-                const bool is_raw = (c == 2 || c == 3) && a.dec.train;
-                const float anc = (c == 2 ? a.dec.aw[an] : a.dec.ah[an]);
-                const int r0 = (NT >= BN) ? tid / BN : 0;
-                int m = bm * BM + rg + r0;
-                int b = m / hw, cell = m - b * hw;
-                int gy = cell / a.dec.G, gx = cell - gy * a.dec.G;
-                for (int r = r0; r < RG && m < M; r += RSTEP, m += RSTEP) {
-                    const float v = T[r * BN + nl];
-                    float o;
-                    if (is_raw) o = v;
-                    else {
-                        const float ex = expf(is_wh ? v : -v);            // one exp serves both kinds
-                        if (is_wh) o = (ex * anc) * a.dec.stride;
-                        else {
-                            o = 1.0f / (1.0f + ex);
-                            if (c < 2 && !a.dec.train) o = (o + (float)(c == 0 ? gx : gy)) * a.dec.stride;
-                        }
-                    }
-                    a.out[(int64_t)b * a.dec.img_stride + a.dec.head_off + (int64_t)(gy * a.dec.G + gx) * a.Cout + n] = o;
-                    gx += RSTEP;
-                    while (gx >= a.dec.G) { gx -= a.dec.G; if (++gy >= a.dec.G) { gy = 0; ++b; } }
-                }
-            }
-        } else {
-            constexpr int GPR = BN / 8;                                   // 8-channel (16-byte) groups per row
-            _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
-            const _Float16* rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
-            for (int g = tid; g < RG * GPR; g += NT) {
-                const int r = g / GPR, c8 = (g - r * GPR) * 8;
-                const int m = bm * BM + rg + r;
-                if (m >= M || bn * BN + c8 >= a.Cout) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + c8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + c8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if constexpr (EPI == EPI_SPLIT_RES) {
-                    const _Float16* q = rh + (int64_t)m * 2 * a.res_ldc + c8;
-                    const f16x8 qh = *reinterpret_cast<const f16x8*>(q);
-                    const f16x8 ql = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
-                }
-                f16x8 ph, pl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const _Float16 h = (_Float16)v[e];
-                    ph[e] = h;
-                    pl[e] = (_Float16)(v[e] - (float)h);
-                }
-                _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
-                *reinterpret_cast<f16x8*>(q) = ph;
-                *reinterpret_cast<f16x8*>(q + a.out_ldc) = pl;
-            }
-        }
-        if (rg + RG < BM) __syncthreads();
-    }
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 }
 
 static const ConvVariantInfo kHVariants[HV_COUNT] = {

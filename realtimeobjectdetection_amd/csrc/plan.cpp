@@ -463,6 +463,8 @@ void Plan::layout_weights() {
             pc.w_off = packed_floats; packed_floats += panel / 2;       // f16 hi plane
             pc.wl_off = packed_floats; packed_floats += panel / 2;      // f16 lo plane
             pc.s_off = packed_floats; packed_floats += pc.Npad;
+            pc.band = conv_band_supported(L.size, L.stride, L.pad, L.cin, L.win) && L.hout == L.hin &&
+                      !(L.fused_into >= 0 && layers[L.fused_into].type == LT_YOLO) && !getenv("RTOD_NO_BAND");
         } else {
             pc.w_off = packed_floats; packed_floats += panel;
         }
@@ -611,7 +613,8 @@ int Plan::load_weights(const float* w, size_t n) {
                             const float vs = (float)((double)v * ps);                                                    // exact (power of two)
                             const uint16_t h = f32_to_f16_rn(vs);
                             const uint16_t l = f32_to_f16_rn(vs - f16_to_f32(h));
-                            const int64_t idx = (int64_t)o * pc.Kpad + (ky * k + kx) * pc.cin_p + c;
+                            // K order of the split kernels: k = ((c/32)*k*k + tap)*32 + c%32 (channel chunk outer, tap inner)
+                            const int64_t idx = (int64_t)o * pc.Kpad + ((c / 32) * k * k + (ky * k + kx)) * 32 + (c % 32);
                             wh[idx] = h; wl[idx] = l;
                         }
             }
@@ -637,6 +640,14 @@ int Plan::choose_variant(const Layer& L, int batch) const {
     const int64_t M = (int64_t)batch * L.hout * L.wout;
     const int64_t big = ((M + 127) / 128) * ((L.cout + 127) / 128);
     return big >= 512 ? CV_128x128 : CV_64x64;     // keep >= 2 workgroups per CU in flight
+}
+
+int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
+    if (v >= BAND_VARIANT_BASE) {
+        if (!pc.band) { set_error("band variant requested for a layer without band weights"); return RTOD_E_STATE; }
+        return launch_conv_band_f16s3(a, v == BAND_VARIANT_BASE ? 128 : 64, s);
+    }
+    return launch_conv_f16s3(a, v, s);
 }
 
 int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const {
@@ -694,13 +705,18 @@ int Plan::autotune(int batch, float* out, hipStream_t s) {
         rc = build_conv_args(l, batch, out, a);
         if (rc) break;
         float best_ms = 1e30f; int best_v = choose_variant_f16s3(L, batch);
-        for (int v = 0; v < HV_COUNT && !rc; ++v) {
+        std::vector<int> cand;
+        for (int v = 0; v < HV_COUNT; ++v) {
             const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
             if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
-            rc = launch_conv_f16s3(a, v, s);                                          // warm-up
+            cand.push_back(v);
+        }
+        if (convs[l.conv_slot].band) { cand.push_back(BAND_VARIANT_BASE); if (L.cout <= 128) cand.push_back(BAND_VARIANT_BASE + 1); }
+        for (int v : cand) {
+            rc = launch_split_variant(a, convs[l.conv_slot], v, s);                   // warm-up
             if (rc) break;
             (void)hipEventRecord(e0, s);
-            for (int r = 0; r < 3 && !rc; ++r) rc = launch_conv_f16s3(a, v, s);
+            for (int r = 0; r < 3 && !rc; ++r) rc = launch_split_variant(a, convs[l.conv_slot], v, s);
             (void)hipEventRecord(e1, s);
             if (rc) break;
             if (hipEventSynchronize(e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "autotune sync"); break; }
@@ -718,6 +734,7 @@ int Plan::autotune(int batch, float* out, hipStream_t s) {
 
 int Plan::variant_for(const Launch& l, int batch) const {
     const char* force = getenv("RTOD_F16S3_VARIANT");
+    if (force && *force && atoi(force) >= BAND_VARIANT_BASE && convs[l.conv_slot].band) return atoi(force);
     if (!(force && *force)) {
         auto it = tuned.find(batch);
         const size_t idx = &l - &launches[0];
@@ -766,7 +783,8 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 ConvArgs a;
                 rc = build_conv_args(l, batch, out, a);
                 if (rc) return rc;
-                rc = pc.split ? launch_conv_f16s3(a, variant_for(l, batch), s) : launch_conv(a, choose_variant(L, batch), s);
+                if (!pc.split) rc = launch_conv(a, choose_variant(L, batch), s);
+                else rc = launch_split_variant(a, pc, variant_for(l, batch), s);
                 break;
             }
             case LK_STEM: {

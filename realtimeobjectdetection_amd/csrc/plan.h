@@ -55,6 +55,7 @@ struct PackedConv {
     int64_t w_off = 0, b_off = 0;     // float offsets into the device weight arena
     bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32
     bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
+    bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
 };
 
@@ -92,6 +93,7 @@ struct Plan {
     int choose_variant_f16s3(const Layer& L, int batch) const;
     int build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const;
     int autotune(int batch, float* out, hipStream_t s);
+    int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)
     std::string describe() const;
