@@ -128,6 +128,12 @@ int rtod_confidence_mask(const float* pred_dev, int64_t rows, int attrs, float c
 int rtod_bbox_iou(const float* box1_dev, const float* boxes_dev, int k, int row_stride,
                   float* iou_dev, void* stream);
 
+/* replaces prep_image + letterbox_image                      src/util.py:349-397
+ * img_dev: uint8 [height,width,3] (HWC; bgr != 0: OpenCV channel order, swapped to RGB like prep_image's
+ * default mode) -> out_dev float32 [3,inp_dim,inp_dim]: aspect-preserving bicubic resize, grey 128 padding,
+ * /255.  cv2 is unavailable offline, so parity with cv2.INTER_CUBIC is unpinned (see preprocess.hip). */
+int rtod_prep_image(const uint8_t* img_dev, int height, int width, int bgr, int inp_dim, float* out_dev, void* stream);
+
 /* replaces write_results                                     src/util.py:242-346
  * pred_dev [batch,n,5+num_class].  Writes detections rows [img,x1,y1,x2,y2,obj,score,cls] to
  * out_dev[cap][8] in the reference's order (image asc, class asc, objectness desc) and

@@ -187,6 +187,12 @@ int rtod_bbox_iou(const float* box1_dev, const float* boxes_dev, int k, int row_
     return launch_bbox_iou(box1_dev, boxes_dev, k, row_stride, iou_dev, (hipStream_t)stream);
 }
 
+int rtod_prep_image(const uint8_t* img_dev, int height, int width, int bgr, int inp_dim, float* out_dev, void* stream) {
+    RTOD_GUARD_BEGIN
+    return launch_prep_image(img_dev, height, width, bgr, inp_dim, out_dev, (hipStream_t)stream);
+    RTOD_GUARD_END
+}
+
 int rtod_write_results_workspace(int batch, int n, size_t* bytes) {
     if (!bytes || batch < 1 || n < 1) { set_error("write_results_workspace: bad args"); return RTOD_E_ARG; }
     *bytes = nms_workspace_bytes(batch, n);

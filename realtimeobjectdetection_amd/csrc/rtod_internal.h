@@ -1,6 +1,7 @@
 // Internal declarations shared by the kernels, the plan and the C ABI (not installed).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -82,6 +83,7 @@ constexpr int BAND_VARIANT_BASE = 50;      // tuned-variant ids >= this select t
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
+int launch_prep_image(const unsigned char* img, int h, int w, int bgr, int inp_dim, float* out, hipStream_t s);
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
 int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s);

@@ -18,6 +18,65 @@ from . import _ffi
 
 _ws_cache = {}
 
+COCO_NAMES = ("person bicycle car motorbike aeroplane bus train truck boat|traffic light|fire hydrant|stop sign|parking meter|bench "
+              "bird cat dog horse sheep cow elephant bear zebra giraffe backpack umbrella handbag tie suitcase frisbee skis snowboard|"
+              "sports ball|kite|baseball bat|baseball glove|skateboard surfboard|tennis racket|bottle|wine glass|cup fork knife spoon bowl "
+              "banana apple sandwich orange broccoli carrot|hot dog|pizza donut cake chair sofa pottedplant bed diningtable toilet "
+              "tvmonitor laptop mouse remote keyboard|cell phone|microwave oven toaster sink refrigerator book clock vase scissors|"
+              "teddy bear|hair drier|toothbrush")
+
+
+def load_classes(names_file_path: str = None) -> list:
+    """Class labels (reference: src/util.py:400-411 reads data/coco.names).  Without a file the 80 COCO names
+    of the Darknet distribution are returned."""
+    if names_file_path:
+        with open(names_file_path, "r") as fp:
+            return fp.read().split("\n")[:-1]
+    out = []
+    for chunk in COCO_NAMES.split("|"):
+        chunk = chunk.strip()
+        if " " in chunk and chunk in ("traffic light", "fire hydrant", "stop sign", "parking meter", "sports ball", "baseball bat",
+                                      "baseball glove", "tennis racket", "wine glass", "hot dog", "cell phone", "teddy bear",
+                                      "hair drier"):
+            out.append(chunk)
+        else:
+            out.extend(chunk.split())
+    return out
+
+
+def prep_image(img, inp_dim, mode="BGR", device=None) -> torch.Tensor:
+    """uint8 HWC image (numpy or torch) -> float32 ``[1,3,inp_dim,inp_dim]`` network input on the GPU
+    (reference: src/util.py:375-397 + letterbox_image 349-372).  Only the uint8 pixels cross PCIe; resize,
+    padding, channel swap and /255 run in a HIP kernel.  ``mode='BGR'`` (OpenCV order, the reference's default)
+    is swapped to RGB.  Parity with cv2.INTER_CUBIC is unpinned (OpenCV is not available offline)."""
+    assert mode == "BGR" or mode == "RGB"
+    t = torch.as_tensor(img)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.size(2) != 3:
+        raise ValueError("prep_image: expected uint8 [H,W,3], got %s %s" % (t.dtype, tuple(t.shape)))
+    if device is None:
+        device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    t = t.to(device).contiguous()
+    out = torch.empty((1, 3, int(inp_dim), int(inp_dim)), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _ffi.check(_ffi.lib().rtod_prep_image(C.c_void_p(t.data_ptr()), t.size(0), t.size(1), 1 if mode == "BGR" else 0,
+                                              int(inp_dim), C.c_void_p(out.data_ptr()), _stream(t.device)))
+    return out
+
+
+def rescale_boxes(output: torch.Tensor, im_dim_list: torch.Tensor, inp_dim: int) -> torch.Tensor:
+    """Undo the letterbox on detection rows ``[img,x1,y1,x2,y2,...]`` and clamp to the image
+    (reference: detect.py:120-136, which hard-codes 416 for the scale; here the actual ``inp_dim``).
+    ``im_dim_list``: ``[n_images, 2]`` = (width, height) per image.  Returns a new tensor."""
+    out = output.clone()
+    dims = im_dim_list.to(out.device, torch.float32)[out[:, 0].long()]
+    scale = torch.min(float(inp_dim) / dims, 1)[0].view(-1, 1)
+    out[:, [1, 3]] -= (inp_dim - scale * dims[:, 0].view(-1, 1)) / 2
+    out[:, [2, 4]] -= (inp_dim - scale * dims[:, 1].view(-1, 1)) / 2
+    out[:, 1:5] /= scale
+    out[:, [1, 3]] = torch.minimum(torch.clamp(out[:, [1, 3]], min=0.0), dims[:, 0].view(-1, 1))
+    out[:, [2, 4]] = torch.minimum(torch.clamp(out[:, [2, 4]], min=0.0), dims[:, 1].view(-1, 1))
+    return out
+
 
 def _need_cuda(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
