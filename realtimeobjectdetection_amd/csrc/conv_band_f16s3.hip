@@ -27,18 +27,42 @@ constexpr int BAND_ROWS = 320;                 // max band rows (128 + 2W + 2 <=
 constexpr int BAND_ZERO = 320;                 // index of the all-zero row
 constexpr int BAND_PANEL = 336 * 64;           // bytes per plane (rows 321..335 unused padding)
 
-template <int BN, int EPI>
-__global__ __launch_bounds__(256, 2)
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 14 && N % 2 == 0, "vmcnt literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+}
+template <typename T, int N> __device__ __forceinline__ void tie_regs(T (&r)[N]) {   // pins later uses below a preceding wait
+    static_assert(N >= 1 && N <= 5, "tie_regs");
+    if constexpr (N == 1) asm volatile("" : "+v"(r[0]) :: "memory");
+    else if constexpr (N == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+    else if constexpr (N == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) :: "memory");
+    else if constexpr (N == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+    else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) :: "memory");
+}
+
+// NWM = waves along M (2: 64x(BN/2) wave tiles, 4 waves; 4: 32x(BN/2) wave tiles, 8 waves at 4 waves/SIMD —
+// the microbenchmark tools/ubench_tiles.hip shows occupancy buys more MFMA utilisation than a larger wave tile)
+template <int BN, int NWM, int EPI>
+__global__ __launch_bounds__(NWM * 128, NWM == 4 ? 4 : 2)
 void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
-    constexpr int BM = 128, WM = 64, WN = BN / 2, NT = 256;
-    constexpr int TM = 2, TN = WN / 32;
-    constexpr int RPP = 64;                                   // rows per pass (4 x 16-B chunks per row)
-    constexpr int B_SLOTS = BN / RPP;
-    constexpr int BAND_SLOTS = BAND_ROWS / RPP;               // 5
+    constexpr int BM = 128, WM = BM / NWM, WN = BN / 2, NT = NWM * 128;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = NT / 4;                               // rows per pass (4 x 16-B chunks per row)
+    constexpr int B_SLOTS = (BN + RPP - 1) / RPP;
+    constexpr int BAND_SLOTS = (BAND_ROWS + RPP - 1) / RPP;   // 5 (4 waves) / 3 (8 waves)
+    static_assert(BN % RPP == 0 || RPP % BN == 0, "B panel / threads");
+    constexpr int B_LOADS = 2 * B_SLOTS, BAND_LOADS = 2 * BAND_SLOTS;
     constexpr int PANEL_B = BN * 64;
     constexpr int BSTAGE = 2 * PANEL_B;
     constexpr int SMEM = 2 * BAND_PANEL + 2 * BSTAGE;
-    static_assert(SMEM >= BM * BN * 4, "epilogue tile must fit");
+    static_assert(SMEM >= WM * BN * 4, "one epilogue row group must fit");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char* bandh = smem;
@@ -75,7 +99,8 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     }
     unsigned wbase[B_SLOTS];
 #pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) wbase[i] = (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u;
+    for (int i = 0; i < B_SLOTS; ++i)
+        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u : OOB;
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
@@ -86,7 +111,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     // ---- per-lane validity of the 9 taps for the two 32-row tiles this wave reads
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;                      // NWM x 2 waves
     const int lr = lane & 31, lh = lane >> 5;
     unsigned vmask[TM];
     int prow[TM];
@@ -135,34 +160,21 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             BRl[j] = asm_buffer_load_b128(rs_a, vo, lo_plane + soff);
         }
     };
-    constexpr int B_LOADS = 2 * B_SLOTS;                       // per stage set
-    // vmcnt literals: N younger loads may stay outstanding
-    // older B set landed; the younger B set (and, for the two steps after a band prefetch was issued, the 10
-    // band loads sitting between them in issue order) may stay in flight
+    // vmcnt bookkeeping (in-order completion).  Steady-state issue pattern: [B set x][B set y] and, right after a
+    // channel-chunk boundary, [B x][B y][band].  wait_b: the older B set has landed, the younger B set (and for the
+    // two steps after a band prefetch the band loads in between) may stay in flight.  The counted wait carries no
+    // register operands (two alternative asm statements with tied operands make the compiler unify their outputs
+    // with copies placed BEFORE the wait); one tying statement after the uniform branch pins the uses instead.
     int band_age = 0;                                          // steps since the last band prefetch was issued
     auto wait_b = [&](BStage& S) {
-        // the counted wait itself carries no register operands: two alternative asm statements with tied
-        // operands make the compiler unify their outputs with copies placed BEFORE the wait (stale data);
-        // one tying statement after the (uniform) branch pins every later use below the wait instead.
-        if constexpr (B_SLOTS == 2) {
-            if (band_age < 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            asm volatile("" : "+v"(S.bh[0]), "+v"(S.bl[0]), "+v"(S.bh[1]), "+v"(S.bl[1]) :: "memory");
-        } else {
-            if (band_age < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            asm volatile("" : "+v"(S.bh[0]), "+v"(S.bl[0]) :: "memory");
-        }
+        if (band_age < 2) wait_vmcnt<B_LOADS + BAND_LOADS>(); else wait_vmcnt<B_LOADS>();
+        tie_regs(S.bh); tie_regs(S.bl);
         ++band_age;
         __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_band = [&]() {                                   // everything issued so far except the two B sets
-        if constexpr (B_SLOTS == 2)
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(BRh[0]), "+v"(BRl[0]), "+v"(BRh[1]), "+v"(BRl[1]), "+v"(BRh[2]), "+v"(BRl[2]),
-                         "+v"(BRh[3]), "+v"(BRl[3]), "+v"(BRh[4]), "+v"(BRl[4]) :: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(BRh[0]), "+v"(BRl[0]), "+v"(BRh[1]), "+v"(BRl[1]), "+v"(BRh[2]), "+v"(BRl[2]),
-                         "+v"(BRh[3]), "+v"(BRl[3]), "+v"(BRh[4]), "+v"(BRl[4]) :: "memory");
+        wait_vmcnt<2 * B_LOADS>();
+        tie_regs(BRh); tie_regs(BRl);
         __builtin_amdgcn_sched_barrier(0);
     };
     const int wr_swz = (c16 ^ ((row0 >> 2) & 3)) << 4;
@@ -171,16 +183,20 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const int o = (row0 + i * RPP) * 64 + wr_swz;
-            *reinterpret_cast<u32x4*>(st + o) = S.bh[i];
-            *reinterpret_cast<u32x4*>(st + PANEL_B + o) = S.bl[i];
+            if ((i + 1) * RPP <= BN || row0 + i * RPP < BN) {
+                *reinterpret_cast<u32x4*>(st + o) = S.bh[i];
+                *reinterpret_cast<u32x4*>(st + PANEL_B + o) = S.bl[i];
+            }
         }
     };
     auto write_band = [&]() {
 #pragma unroll
         for (int j = 0; j < BAND_SLOTS; ++j) {
             const int o = (row0 + j * RPP) * 64 + wr_swz;
-            *reinterpret_cast<u32x4*>(bandh + o) = BRh[j];
-            *reinterpret_cast<u32x4*>(bandl + o) = BRl[j];
+            if ((j + 1) * RPP <= BAND_ROWS || row0 + j * RPP < BAND_ROWS) {     // never touch the zero row / padding
+                *reinterpret_cast<u32x4*>(bandh + o) = BRh[j];
+                *reinterpret_cast<u32x4*>(bandl + o) = BRl[j];
+            }
         }
     };
 
@@ -194,8 +210,11 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     const int rd_swz = (lr >> 2) & 3;
     const int b_row = (wn * WN + lr) * 64;
-    struct Frags { f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN]; };
-    auto read_frags = [&](int tap, int buf, Frags& F) {
+    // 4-wave blocks read the fragments of both k16 steps up front (64 VGPRs); 8-wave blocks must stay within
+    // 128 VGPRs for 4 waves/SIMD and read one k16 step at a time (the other waves of the SIMD cover the latency)
+    constexpr int FK = (NWM == 4) ? 1 : 2;
+    struct Frags { f16x8 ah[FK][TM], al[FK][TM], bh[FK][TN], bl[FK][TN]; };
+    auto read_frags = [&](int tap, int buf, int ks0, Frags& F) {
         const int shift = (tap / 3) * W + (tap % 3);
         const unsigned char* st = bst + buf * BSTAGE;
 #pragma unroll
@@ -204,32 +223,32 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             const bool ok = (vmask[i] >> tap) & 1u;
             const int swz = (row >> 2) & 3;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int o = ok ? row * 64 + (((ks * 2 + lh) ^ swz) << 4) : BAND_ZERO * 64;
-                F.ah[ks][i] = *reinterpret_cast<const f16x8*>(bandh + o);
-                F.al[ks][i] = *reinterpret_cast<const f16x8*>(bandl + o);
+            for (int k = 0; k < FK; ++k) {
+                const int o = ok ? row * 64 + ((((ks0 + k) * 2 + lh) ^ swz) << 4) : BAND_ZERO * 64;
+                F.ah[k][i] = *reinterpret_cast<const f16x8*>(bandh + o);
+                F.al[k][i] = *reinterpret_cast<const f16x8*>(bandl + o);
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 2 + lh) ^ rd_swz) << 4;
+        for (int k = 0; k < FK; ++k) {
+            const int co = (((ks0 + k) * 2 + lh) ^ rd_swz) << 4;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                F.bh[ks][j] = *reinterpret_cast<const f16x8*>(st + b_row + j * 32 * 64 + co);
-                F.bl[ks][j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + b_row + j * 32 * 64 + co);
+                F.bh[k][j] = *reinterpret_cast<const f16x8*>(st + b_row + j * 32 * 64 + co);
+                F.bl[k][j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + b_row + j * 32 * 64 + co);
             }
         }
     };
     auto mfma_block = [&](const Frags& F) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int k = 0; k < FK; ++k)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bl[ks][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bl[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
                 }
     };
 
@@ -252,12 +271,13 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
     auto step = [&](int buf, BStage& Snext) {
-        read_frags(tap, buf, F);
+        read_frags(tap, buf, 0, F);
         wait_b(Snext);
         write_b(Snext, buf ^ 1);
         gload_b(Snext);
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(F);
+        if constexpr (FK == 1) { read_frags(tap, buf, 1, F); mfma_block(F); }
         __syncthreads();
         if (++tap == 9) {
             tap = 0; ++cc;
@@ -281,14 +301,14 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, SMEM>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 }
 
-template <int BN>
+template <int BN, int NWM>
 static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + 127) / 128, gn = (a.Cout + BN - 1) / BN;
     if (a.res)
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, EPI_SPLIT_RES>), dim3(gm * gn), dim3(256), 0, s, a, gm, gn);
+        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, NWM, EPI_SPLIT_RES>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
     else
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, EPI_SPLIT>), dim3(gm * gn), dim3(256), 0, s, a, gm, gn);
+        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, NWM, EPI_SPLIT>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_band_f16s3 launch");
 }
 
@@ -296,7 +316,7 @@ bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && 128 + 2 * w_in + 2 <= BAND_ROWS;
 }
 
-int launch_conv_band_f16s3(const ConvArgs& a_in, int bn, hipStream_t s) {
+int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {      // mode: 0 128x128/4w, 1 128x64/4w, 2 128x128/8w, 3 128x64/8w
     ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_band: null pointer"); return RTOD_E_ARG; }
     if (!conv_band_supported(a.kh, a.stride, a.pad, a.Cin, a.Wi) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled) {
@@ -309,9 +329,11 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int bn, hipStream_t s) {
     if (dbg_zero & 1) a.in_bytes = 1;
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
-    if (bn == 128) return launch_band<128>(a, s);
-    if (bn == 64) return launch_band<64>(a, s);
-    set_error("launch_conv_band: BN %d unsupported", bn);
+    if (mode == 0) return launch_band<128, 2>(a, s);
+    if (mode == 1) return launch_band<64, 2>(a, s);
+    if (mode == 2) return launch_band<128, 4>(a, s);
+    if (mode == 3) return launch_band<64, 4>(a, s);
+    set_error("launch_conv_band: mode %d unsupported", mode);
     return RTOD_E_ARG;
 }
 

@@ -33,10 +33,13 @@ struct StageRegs {
     u32x4 ah[ASL], al[ASL], bh[BSL], bl[BSL];
 };
 
+// Waves per SIMD the register budget must admit (2nd __launch_bounds__ argument): wave tiles of 32x64 or smaller
+// (<= 32 accumulator registers) are built for 4 waves/SIMD — tools/ubench_tiles.hip: occupancy buys more MFMA
+// utilisation than a larger wave tile — the 64x64 wave tiles need ~220 registers and run at 2.
+constexpr int igemm_min_waves(int wm, int wn) { return (wm / 32) * (wn / 32) <= 2 ? 4 : 2; }
+
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 8 ? 2 : ((BM / WM) * (BN / WN) == 6 ? 3 : 2)))
-// second argument = waves per SIMD the register budget must admit: 8-wave tiles run one workgroup per CU
-// (2 waves/SIMD), 6-wave tiles two workgroups (3 waves/SIMD), 4-wave tiles two or more.
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, igemm_min_waves(WM, WN))
 void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
     constexpr int NWN = BN / WN;
     constexpr int NT = (BM / WM) * NWN * 64;
@@ -180,34 +183,35 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // chunk's LDS writes and the global loads of the chunk after are issued, and only then the 24-MFMA
     // block runs: the LDS write drain (~80 B/clk/CU through the VGPR path) and the load latency overlap
     // with the matrix pipe instead of sitting between the MFMAs and the barrier.
-    struct Frags { f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN]; };
-    auto read_frags = [&](int buf, Frags& F) {
+    constexpr int FK = igemm_min_waves(WM, WN) == 4 ? 1 : 2;       // k16 steps of fragments held at once
+    struct Frags { f16x8 ah[FK][TM], al[FK][TM], bh[FK][TN], bl[FK][TN]; };
+    auto read_frags = [&](int buf, int ks0, Frags& F) {
         const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 2 + lh) ^ rd_swz) << 4;
+        for (int k = 0; k < FK; ++k) {
+            const int co = (((ks0 + k) * 2 + lh) ^ rd_swz) << 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                F.ah[ks][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 64 + co);
-                F.al[ks][i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + a_row + i * 32 * 64 + co);
+                F.ah[k][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 64 + co);
+                F.al[k][i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + a_row + i * 32 * 64 + co);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                F.bh[ks][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + b_row + j * 32 * 64 + co);
-                F.bl[ks][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + PANEL_B + b_row + j * 32 * 64 + co);
+                F.bh[k][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + b_row + j * 32 * 64 + co);
+                F.bl[k][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + PANEL_B + b_row + j * 32 * 64 + co);
             }
         }
     };
     auto mfma_block = [&](const Frags& F) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int k = 0; k < FK; ++k)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bl[ks][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[ks][i], F.bh[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bl[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
                 }
     };
 
@@ -224,19 +228,21 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     __syncthreads();
     Frags F;
     for (int t = 0; t < nk; t += 2) {
-        read_frags(0, F);                             // chunk t
+        read_frags(0, 0, F);                          // chunk t
         wait_stage(S1);
         lds_write(S1, 1);                             // chunk t+1
         gload(S1);                                    // chunk t+3
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(F);
+        if constexpr (FK == 1) { read_frags(0, 1, F); mfma_block(F); }
         __syncthreads();
-        read_frags(1, F);                             // chunk t+1
+        read_frags(1, 0, F);                          // chunk t+1
         wait_stage(S0);
         lds_write(S0, 0);                             // chunk t+2
         gload(S0);                                    // chunk t+4
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(F);
+        if constexpr (FK == 1) { read_frags(1, 1, F); mfma_block(F); }
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
@@ -252,6 +258,9 @@ static const ConvVariantInfo kHVariants[HV_COUNT] = {
     {64, 128, "conv_igemm_f16s3<64x128,w32x64>"},
     {256, 128, "conv_igemm_f16s3<256x128,w64x64>"},
     {128, 256, "conv_igemm_f16s3<128x256,w64x64>"},
+    {128, 128, "conv_igemm_f16s3<128x128,w32x64>"},
+    {128, 64, "conv_igemm_f16s3<128x64,w32x32>"},
+    {256, 128, "conv_igemm_f16s3<256x128,w32x64>"},
 };
 
 const ConvVariantInfo& conv_f16s3_variant_info(int v) { return kHVariants[v < 0 || v >= HV_COUNT ? 0 : v]; }
@@ -295,6 +304,9 @@ int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
         case HV_64x128: return launch_h<64, 128, 32, 64>(a, s);
         case HV_256x128: return launch_h<256, 128, 64, 64>(a, s);
         case HV_128x256: return launch_h<128, 256, 64, 64>(a, s);
+        case HV_128x128_8W: return launch_h<128, 128, 32, 64>(a, s);
+        case HV_128x64_8W: return launch_h<128, 64, 32, 32>(a, s);
+        case HV_256x128_16W: return launch_h<256, 128, 32, 64>(a, s);
     }
     set_error("launch_conv_f16s3: unknown variant %d", variant);
     return RTOD_E_ARG;

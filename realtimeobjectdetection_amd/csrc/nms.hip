@@ -29,7 +29,7 @@ constexpr int NMS_BLOCK = 1024;
 
 struct NmsWs {
     int32_t* cand;        // [B]  sortable candidates per image (score != 0)
-    int32_t* cand_all;    // [1]  rows with obj > conf over the batch
+    int32_t* cand_all;    // [B]  rows with obj > conf per image (one word per image: a single word serialises ~2000 atomics)
     int32_t* ndet;        // [B]  survivors per image
     uint64_t* keys;       // [B][P]  P = pow2 >= n
     uint8_t* alive;       // [B][P]
@@ -45,7 +45,7 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t nms_workspace_bytes(int batch, int n) {
     const size_t P = next_pow2(n < 1 ? 1 : n);
     size_t b = 0;
-    b += align256(sizeof(int32_t) * (2 * (size_t)batch + 4));
+    b += align256(sizeof(int32_t) * (3 * (size_t)batch + 4));
     b += align256(sizeof(uint64_t) * batch * P);
     b += align256(batch * P);
     b += align256(sizeof(int32_t) * (size_t)batch * (NMS_MAX_CLASSES + 1));
@@ -59,8 +59,8 @@ static NmsWs carve(void* ws, int batch, int n) {
     char* p = (char*)ws;
     w.cand = (int32_t*)p;
     w.cand_all = w.cand + batch;
-    w.ndet = w.cand + batch + 4;
-    p += align256(sizeof(int32_t) * (2 * (size_t)batch + 4));
+    w.ndet = w.cand + 2 * batch + 4;
+    p += align256(sizeof(int32_t) * (3 * (size_t)batch + 4));
     w.keys = (uint64_t*)p; p += align256(sizeof(uint64_t) * batch * P);
     w.alive = (uint8_t*)p; p += align256(batch * P);
     w.segs = (int32_t*)p; p += align256(sizeof(int32_t) * (size_t)batch * (NMS_MAX_CLASSES + 1));
@@ -94,7 +94,7 @@ void nms_filter_kernel(const float* __restrict__ pred, int B, int n, int num_cla
         pass = (obj > conf) && (obj != 0.0f);      // mask (strict >), then nonzero(obj)  util.py:116,286
     }
     unsigned long long mask = __ballot(pass);
-    if (lane == 0 && mask) atomicAdd(w.cand_all, __popcll(mask));
+    if (lane == 0 && mask) atomicAdd(&w.cand_all[b], __popcll(mask));
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -248,7 +248,7 @@ void nms_emit_kernel(int B, int n, NmsWs w, float* __restrict__ out, int cap, in
     const int nd = w.ndet[b];
     if (threadIdx.x == 0) {
         counts[2 + b] = nd;
-        if (b == 0) { counts[0] = total; counts[1] = *w.cand_all; }
+        if (b == 0) { int ca = 0; for (int i = 0; i < B; ++i) ca += w.cand_all[i]; counts[0] = total; counts[1] = ca; }
     }
     const uint64_t* gk = w.keys + (int64_t)b * w.P;
     const float* rec = w.rec + (int64_t)b * n * 8;
@@ -275,7 +275,7 @@ int launch_write_results(const float* pred, int batch, int n, int num_class, flo
     if (ws_bytes < nms_workspace_bytes(batch, n)) { set_error("write_results: workspace too small"); return RTOD_E_ARG; }
     if (((uintptr_t)ws & 15) || ((uintptr_t)out & 15)) { set_error("write_results: workspace/out must be 16-byte aligned"); return RTOD_E_ARG; }
     NmsWs w = carve(ws, batch, n);
-    RTOD_HIP(hipMemsetAsync(w.cand, 0, sizeof(int32_t) * (2 * (size_t)batch + 4), s));
+    RTOD_HIP(hipMemsetAsync(w.cand, 0, sizeof(int32_t) * (3 * (size_t)batch + 4), s));
     const int waves = batch * ((n + 63) / 64);
     hipLaunchKernelGGL(nms_filter_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, pred, batch, n, num_class, conf, w);
     hipLaunchKernelGGL(nms_sort_suppress_kernel, dim3(batch), dim3(NMS_BLOCK), 0, s, n, nms, w);

@@ -645,7 +645,7 @@ int Plan::choose_variant(const Layer& L, int batch) const {
 int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
     if (v >= BAND_VARIANT_BASE) {
         if (!pc.band) { set_error("band variant requested for a layer without band weights"); return RTOD_E_STATE; }
-        return launch_conv_band_f16s3(a, v == BAND_VARIANT_BASE ? 128 : 64, s);
+        return launch_conv_band_f16s3(a, v - BAND_VARIANT_BASE, s);
     }
     return launch_conv_f16s3(a, v, s);
 }
@@ -711,7 +711,10 @@ int Plan::autotune(int batch, float* out, hipStream_t s) {
             if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
             cand.push_back(v);
         }
-        if (convs[l.conv_slot].band) { cand.push_back(BAND_VARIANT_BASE); if (L.cout <= 128) cand.push_back(BAND_VARIANT_BASE + 1); }
+        if (convs[l.conv_slot].band) {
+            cand.push_back(BAND_VARIANT_BASE); cand.push_back(BAND_VARIANT_BASE + 2);
+            if (L.cout <= 128) { cand.push_back(BAND_VARIANT_BASE + 1); cand.push_back(BAND_VARIANT_BASE + 3); }
+        }
         for (int v : cand) {
             rc = launch_split_variant(a, convs[l.conv_slot], v, s);                   // warm-up
             if (rc) break;
