@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtod.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("RTOD_LIB", "librtod.so"))   # RTOD_LIB: A/B an alternative build (dev only)
 
 
 class RtodError(RuntimeError):

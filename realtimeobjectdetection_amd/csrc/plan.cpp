@@ -651,87 +651,79 @@ int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStre
 }
 
 int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const {
-                const Layer& L = layers[l.layer];
-                const PackedConv& pc = convs[l.conv_slot];
-                const View in = view_of(l.in_layer);
-                a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
-                a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
-                a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
-                a.in_bytes = (unsigned)std::min<int64_t>((int64_t)batch * in.H * in.W * in.ldc * 4, 0xFFFFFFFFll);
-                a.w_bytes = (unsigned)std::min<int64_t>((int64_t)pc.Npad * pc.Kpad * 2, 0xFFFFFFFFll);
-                if (pc.split) {
-                    a.w_hi = reinterpret_cast<const _Float16*>(d_weights + pc.w_off);
-                    a.w_lo = reinterpret_cast<const _Float16*>(d_weights + pc.wl_off);
-                    a.inv_scale = d_weights + pc.s_off;
-                }
-                a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
-                a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
-                if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
-                if (l.out_layer == -2) { a.out = out; a.dec = l.dec; a.dec.train = train_decode; }
-                else {
-                    const View o = view_of(l.out_layer);
-                    if (!o.base || o.C != L.cout || o.H != L.hout || o.W != L.wout) { set_error("forward: layer %d output view mismatch", l.layer); return RTOD_E_STATE; }
-                    a.out = o.base; a.out_ldc = o.ldc; a.out_coff = o.coff; a.out_split = o.split;
-                }
-                if (l.in2_layer >= 0) {
-                    const View r = view_of(l.in2_layer);
-                    if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
-                    a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
-                }
+    const Layer& L = layers[l.layer];
+    const PackedConv& pc = convs[l.conv_slot];
+    const View in = view_of(l.in_layer);
+    a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
+    a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
+    a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
+    a.in_bytes = (unsigned)std::min<int64_t>((int64_t)batch * in.H * in.W * in.ldc * 4, 0xFFFFFFFFll);
+    a.w_bytes = (unsigned)std::min<int64_t>((int64_t)pc.Npad * pc.Kpad * 2, 0xFFFFFFFFll);
+    if (pc.split) {
+        a.w_hi = reinterpret_cast<const _Float16*>(d_weights + pc.w_off);
+        a.w_lo = reinterpret_cast<const _Float16*>(d_weights + pc.wl_off);
+        a.inv_scale = d_weights + pc.s_off;
+    }
+    a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
+    a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
+    if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
+    if (l.out_layer == -2) { a.out = out; a.dec = l.dec; a.dec.train = train_decode; }
+    else {
+        const View o = view_of(l.out_layer);
+        if (!o.base || o.C != L.cout || o.H != L.hout || o.W != L.wout) { set_error("forward: layer %d output view mismatch", l.layer); return RTOD_E_STATE; }
+        a.out = o.base; a.out_ldc = o.ldc; a.out_coff = o.coff; a.out_split = o.split;
+    }
+    if (l.in2_layer >= 0) {
+        const View r = view_of(l.in2_layer);
+        if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
+        a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
+    }
     return RTOD_OK;
 }
 
-// Autotune: for every distinct conv shape of this batch size, time each split-f16 tile variant on the
-// device (3 timed launches after 1 warm-up, HIP events on `s`) and remember the fastest.  Tile choice
-// interacts with the 256-CU round structure (a 722-block grid on 512 resident slots runs two rounds at
-// 70 % efficiency) in ways a closed-form heuristic keeps getting wrong; measuring takes ~0.2 s once.
-int Plan::autotune(int batch, float* out, hipStream_t s) {
-    if (precision != 1) return RTOD_OK;
-    if (tuned.count(batch)) return RTOD_OK;
-    std::vector<int> best(launches.size(), -1);
-    if (getenv("RTOD_NO_AUTOTUNE")) { tuned[batch] = best; return RTOD_OK; }
-    std::map<std::vector<int>, int> cache;
+// Autotune: at the first forward of a batch size every distinct split-f16 conv shape times each tile variant /
+// kernel on the device (1 warm-up, then the minimum of 3 timed pairs, HIP events on `s`) and remembers the fastest.
+// It runs INSIDE that forward, layer by layer, so each candidate sees the layer's real input (timing on a zeroed
+// arena ranks kernels differently: zero operands change the clock the chip holds).  Tile choice interacts with the
+// 256-CU round structure (a 722-block grid on 512 resident slots runs two rounds at 70 % efficiency) in ways a
+// closed-form heuristic keeps getting wrong; measuring costs ~0.3 s once per batch size.
+int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
+    const Launch& l = launches[li];
+    const Layer& L = layers[l.layer];
+    const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2};
+    auto it = tune_cache.find(key);
+    if (it != tune_cache.end()) { tuning[li] = it->second; return RTOD_OK; }
     hipEvent_t e0, e1;
     RTOD_HIP(hipEventCreate(&e0)); RTOD_HIP(hipEventCreate(&e1));
+    std::vector<int> cand;
+    for (int v = 0; v < HV_COUNT; ++v) {
+        const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
+        if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;           // tile far wider than the layer
+        cand.push_back(v);
+    }
+    if (convs[l.conv_slot].band) for (int m = 0; m < 4; ++m) cand.push_back(BAND_VARIANT_BASE + m);
+    float best_ms = 1e30f; int best_v = choose_variant_f16s3(L, batch);
     int rc = RTOD_OK;
-    for (size_t li = 0; li < launches.size() && !rc; ++li) {
-        const Launch& l = launches[li];
-        if (l.kind != LK_CONV || !convs[l.conv_slot].split) continue;
-        const Layer& L = layers[l.layer];
-        const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2};
-        auto it = cache.find(key);
-        if (it != cache.end()) { best[li] = it->second; continue; }
-        ConvArgs a;
-        rc = build_conv_args(l, batch, out, a);
+    for (int v : cand) {
+        rc = launch_split_variant(a, convs[l.conv_slot], v, s);                       // warm-up
         if (rc) break;
-        float best_ms = 1e30f; int best_v = choose_variant_f16s3(L, batch);
-        std::vector<int> cand;
-        for (int v = 0; v < HV_COUNT; ++v) {
-            const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
-            if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
-            cand.push_back(v);
-        }
-        if (convs[l.conv_slot].band) {
-            cand.push_back(BAND_VARIANT_BASE); cand.push_back(BAND_VARIANT_BASE + 2);
-            if (L.cout <= 128) { cand.push_back(BAND_VARIANT_BASE + 1); cand.push_back(BAND_VARIANT_BASE + 3); }
-        }
-        for (int v : cand) {
-            rc = launch_split_variant(a, convs[l.conv_slot], v, s);                   // warm-up
-            if (rc) break;
+        float vmin = 1e30f;
+        for (int rep = 0; rep < 3 && !rc; ++rep) {
             (void)hipEventRecord(e0, s);
-            for (int r = 0; r < 3 && !rc; ++r) rc = launch_split_variant(a, convs[l.conv_slot], v, s);
+            for (int r = 0; r < 2 && !rc; ++r) rc = launch_split_variant(a, convs[l.conv_slot], v, s);
             (void)hipEventRecord(e1, s);
             if (rc) break;
             if (hipEventSynchronize(e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "autotune sync"); break; }
             float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-            if (ms < best_ms) { best_ms = ms; best_v = v; }
+            vmin = std::min(vmin, ms);
         }
-        best[li] = best_v;
-        cache[key] = best_v;
+        if (rc) break;
+        if (vmin < best_ms) { best_ms = vmin; best_v = v; }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc) return rc;
-    tuned[batch] = best;
+    tuning[li] = best_v;
+    tune_cache[key] = best_v;
     return RTOD_OK;
 }
 
@@ -762,10 +754,8 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
     if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
     if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
     RTOD_HIP(hipSetDevice(device));
-    {
-        const int rc0 = autotune(batch, out, s);       // first forward of a batch size only (synchronises once)
-        if (rc0) return rc0;
-    }
+    const bool tune_now = precision == 1 && !tuned.count(batch) && !getenv("RTOD_NO_AUTOTUNE");   // first forward of a batch size
+    if (tune_now) { tuning.assign(launches.size(), -1); tune_cache.clear(); }
     const size_t nl = launches.size();
     if (launch_ms && events.size() < 2 * nl) {
         while (events.size() < 2 * nl) { hipEvent_t e; RTOD_HIP(hipEventCreate(&e)); events.push_back(e); }
@@ -787,7 +777,10 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 rc = build_conv_args(l, batch, out, a);
                 if (rc) return rc;
                 if (!pc.split) rc = launch_conv(a, choose_variant(L, batch), s);
-                else rc = launch_split_variant(a, pc, variant_for(l, batch), s);
+                else {
+                    if (tune_now) { rc = tune_launch(li, a, batch, s); if (rc) return rc; }
+                    rc = launch_split_variant(a, pc, tune_now && tuning[li] >= 0 ? tuning[li] : variant_for(l, batch), s);
+                }
                 break;
             }
             case LK_STEM: {
@@ -819,6 +812,8 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
         if (rc) return rc;
         if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li + 1], s));
     }
+    if (tune_now) tuned[batch] = tuning;
+    else if (precision == 1 && !tuned.count(batch)) tuned[batch] = std::vector<int>(launches.size(), -1);
     if (launch_ms) {
         RTOD_HIP(hipEventSynchronize(events[2 * nl - 1]));
         for (size_t li = 0; li < nl; ++li) RTOD_HIP(hipEventElapsedTime(&launch_ms[li], events[2 * li], events[2 * li + 1]));

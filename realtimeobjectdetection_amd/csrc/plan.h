@@ -92,7 +92,9 @@ struct Plan {
     int choose_variant(const Layer& L, int batch) const;
     int choose_variant_f16s3(const Layer& L, int batch) const;
     int build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) const;
-    int autotune(int batch, float* out, hipStream_t s);
+    int tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s);
+    std::vector<int> tuning;                    // scratch of the tuning forward
+    std::map<std::vector<int>, int> tune_cache;
     int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)
