@@ -313,3 +313,27 @@ def test_state_dict_roundtrip(tmp_path_factory):
     x = torch.from_numpy(synth.synth_frames(1, 416)).cuda()
     with torch.no_grad():
         assert torch.equal(m(x), m2(x))
+
+
+def test_heuristic_variants_without_autotune_and_batch_growth(tmp_path_factory, monkeypatch, golden_dir):
+    """RTOD_NO_AUTOTUNE=1 runs the closed-form tile heuristics; a larger batch than the plan was built for
+    rebuilds the plan (re-packing the weights) transparently.  Both must keep parity."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    monkeypatch.setenv("RTOD_NO_AUTOTUNE", "1")
+    d = tmp_path_factory.mktemp("heur")
+    cfg_text = NETS["yolov3"]()
+    m = Darknet(cfgs.write_cfg(str(d / "yolov3.cfg"), cfg_text), True).eval()
+    m.net_info["height"] = 416
+    ref = O.RefDarknet(cfg_text, 416)
+    w = synth.synth_weights(ref.ir)
+    m.load_weight_stream(w)
+    g = np.load(os.path.join(golden_dir, "fwd_yolov3_416_b2.npz"))
+    x = torch.from_numpy(synth.synth_frames(2, 416)).cuda()
+    with torch.no_grad():
+        y1 = m(x[:1])                                  # plan for max_batch 1
+        assert m._plan_key[1] == 1
+        y2 = m(x)                                      # grows to 2: new plan, weights re-packed
+        assert m._plan_key[1] == 2
+    rows = y2[:, ::int(g["row_stride"]), :].cpu().numpy()
+    assert rel_err(rows, g["rows"]).max() <= TOL
+    assert rel_err(y1.cpu().numpy(), y2[:1].cpu().numpy()).max() <= 5e-5
