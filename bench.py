@@ -100,7 +100,7 @@ def rocprof_kernel_name(tile_name, epi):
     import re
     mb = re.match(r"conv_band_f16s3<(\d+)x(\d+),(\d)w>", tile_name)
     if mb:
-        return "void rtod::conv_band_f16s3_kernel<%d, %d, %d>(rtod::ConvArgs, int, int)" % (int(mb.group(2)), int(mb.group(3)) // 2, epi)
+        return "void rtod::conv_band_f16s3_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (int(mb.group(1)), int(mb.group(2)), int(mb.group(3)) // 2, epi)
     m = re.match(r"conv_igemm_(f16s3|f32)<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
     kind, bm, bn, wm, wn = m.group(1), *[int(v) for v in m.groups()[1:]]
     if kind == "f16s3":

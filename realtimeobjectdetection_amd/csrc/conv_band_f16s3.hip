@@ -47,17 +47,24 @@ template <typename T, int N> __device__ __forceinline__ void tie_regs(T (&r)[N])
     else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) :: "memory");
 }
 
-// NWM = waves along M (2: 64x(BN/2) wave tiles, 4 waves; 4: 32x(BN/2) wave tiles, 8 waves at 4 waves/SIMD —
-// the microbenchmark tools/ubench_tiles.hip shows occupancy buys more MFMA utilisation than a larger wave tile)
-template <int BN, int NWM, int EPI>
-__global__ __launch_bounds__(NWM * 128, NWM == 4 ? 4 : 2)
+// BM = output pixels per workgroup, NWM = waves along M (x 2 waves along N).
+//   BM 128, NWM 2: 4 waves of 64 x BN/2 (2 waves/SIMD)
+//   BM 128, NWM 4: 8 waves of 32 x BN/2 at 4 waves/SIMD — tools/ubench_tiles.hip: occupancy buys more MFMA
+//                  utilisation than a larger wave tile
+//   BM  96, NWM 3: 6 waves of 32 x BN/2 at 3 waves/SIMD — a tile height that fills whole rounds of the 512 resident
+//                  workgroup slots where 128 does not (38x38x8 x 512 ch: 484 tiles instead of 364)
+constexpr int band_min_waves(int nwm) { return nwm == 4 ? 4 : (nwm == 3 ? 3 : 2); }
+
+template <int BM, int BN, int NWM, int EPI>
+__global__ __launch_bounds__(NWM * 128, band_min_waves(NWM))
 void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
-    constexpr int BM = 128, WM = BM / NWM, WN = BN / 2, NT = NWM * 128;
+    constexpr int WM = BM / NWM, WN = BN / 2, NT = NWM * 128;
+    static_assert(WM % 32 == 0 && BM + 2 * 94 + 2 <= BAND_ROWS + 64, "band tile");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = NT / 4;                               // rows per pass (4 x 16-B chunks per row)
     constexpr int B_SLOTS = (BN + RPP - 1) / RPP;
     constexpr int BAND_SLOTS = (BAND_ROWS + RPP - 1) / RPP;   // 5 (4 waves) / 3 (8 waves)
-    static_assert(BN % RPP == 0 || RPP % BN == 0, "B panel / threads");
+    static_assert(RPP % 16 == 0, "a pass that runs past a panel is predicated per 16-row wave slice");
     constexpr int B_LOADS = 2 * B_SLOTS, BAND_LOADS = 2 * BAND_SLOTS;
     constexpr int PANEL_B = BN * 64;
     constexpr int BSTAGE = 2 * PANEL_B;
@@ -212,7 +219,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int b_row = (wn * WN + lr) * 64;
     // 4-wave blocks read the fragments of both k16 steps up front (64 VGPRs); 8-wave blocks must stay within
     // 128 VGPRs for 4 waves/SIMD and read one k16 step at a time (the other waves of the SIMD cover the latency)
-    constexpr int FK = (NWM == 4) ? 1 : 2;
+    constexpr int FK = (NWM >= 3) ? 1 : 2;
     struct Frags { f16x8 ah[FK][TM], al[FK][TM], bh[FK][TN], bl[FK][TN]; };
     auto read_frags = [&](int tap, int buf, int ks0, Frags& F) {
         const int shift = (tap / 3) * W + (tap % 3);
@@ -301,22 +308,23 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, SMEM>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 }
 
-template <int BN, int NWM>
+template <int BM, int BN, int NWM>
 static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
-    const int gm = (M + 127) / 128, gn = (a.Cout + BN - 1) / BN;
+    const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
     if (a.res)
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, NWM, EPI_SPLIT_RES>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
+        hipLaunchKernelGGL((conv_band_f16s3_kernel<BM, BN, NWM, EPI_SPLIT_RES>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
     else
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BN, NWM, EPI_SPLIT>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
+        hipLaunchKernelGGL((conv_band_f16s3_kernel<BM, BN, NWM, EPI_SPLIT>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_band_f16s3 launch");
 }
 
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
-    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && 128 + 2 * w_in + 2 <= BAND_ROWS;
+    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && 128 + 2 * w_in + 2 <= BAND_ROWS;   // BM <= 128
 }
 
-int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {      // mode: 0 128x128/4w, 1 128x64/4w, 2 128x128/8w, 3 128x64/8w
+// mode: 0 128x128/4w, 1 128x64/4w, 2 128x128/8w, 3 128x64/8w, 4 96x128/6w, 5 96x64/6w
+int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_band: null pointer"); return RTOD_E_ARG; }
     if (!conv_band_supported(a.kh, a.stride, a.pad, a.Cin, a.Wi) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled) {
@@ -329,10 +337,12 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {     
     if (dbg_zero & 1) a.in_bytes = 1;
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
-    if (mode == 0) return launch_band<128, 2>(a, s);
-    if (mode == 1) return launch_band<64, 2>(a, s);
-    if (mode == 2) return launch_band<128, 4>(a, s);
-    if (mode == 3) return launch_band<64, 4>(a, s);
+    if (mode == 0) return launch_band<128, 128, 2>(a, s);
+    if (mode == 1) return launch_band<128, 64, 2>(a, s);
+    if (mode == 2) return launch_band<128, 128, 4>(a, s);
+    if (mode == 3) return launch_band<128, 64, 4>(a, s);
+    if (mode == 4) return launch_band<96, 128, 3>(a, s);
+    if (mode == 5) return launch_band<96, 64, 3>(a, s);
     set_error("launch_conv_band: mode %d unsupported", mode);
     return RTOD_E_ARG;
 }

@@ -79,7 +79,7 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 // 3x3 stride-1 pad-1 convs with an LDS-resident input band (conv_band_f16s3.hip); weights in band K order
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 int launch_conv_band_f16s3(const ConvArgs& a, int mode, hipStream_t s);
-constexpr int BAND_VARIANT_BASE = 50;      // tuned-variant ids >= this select the band kernel: +0 128x128/4 waves, +1 128x64/4w, +2 128x128/8w, +3 128x64/8w
+constexpr int BAND_VARIANT_BASE = 50;      // tuned-variant ids >= this select the band kernel: +0 128x128/4 waves, +1 128x64/4w, +2 128x128/8w, +3 128x64/8w, +4 96x128/6w, +5 96x64/6w
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
