@@ -98,9 +98,11 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=25.0):
 def rocprof_kernel_name(tile_name, epi):
     """'conv_igemm_f16s3<128x128,w64x64>' + epilogue id -> the demangled name rocprofv3 prints."""
     import re
-    mb = re.match(r"conv_band_f16s3<(\d+)x(\d+),(\d)w>", tile_name)
+    mb = re.match(r"conv_band_f16s3<(\d+)x(\d+),(\d)x(\d)>", tile_name)
     if mb:
-        return "void rtod::conv_band_f16s3_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (int(mb.group(1)), int(mb.group(2)), int(mb.group(3)) // 2, epi)
+        bm, bn, nwm, nwn = [int(v) for v in mb.groups()]
+        minw = {(192, 128): 3, (128, 128): 4 if nwm == 4 else 2}.get((bm, bn), 4)     # launch_conv_band_f16s3's MINW per mode
+        return "void rtod::conv_band_f16s3_kernel<%d, %d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, nwm, nwn, minw, epi)
     m = re.match(r"conv_igemm_(f16s3|f32)<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
     kind, bm, bn, wm, wn = m.group(1), *[int(v) for v in m.groups()[1:]]
     if kind == "f16s3":

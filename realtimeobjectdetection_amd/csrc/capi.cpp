@@ -92,12 +92,7 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 }
 
 const char* rtod_conv_variant_name(int variant) {
-    if (variant == 100 + BAND_VARIANT_BASE) return "conv_band_f16s3<128x128,4w>";
-    if (variant == 100 + BAND_VARIANT_BASE + 1) return "conv_band_f16s3<128x64,4w>";
-    if (variant == 100 + BAND_VARIANT_BASE + 2) return "conv_band_f16s3<128x128,8w>";
-    if (variant == 100 + BAND_VARIANT_BASE + 3) return "conv_band_f16s3<128x64,8w>";
-    if (variant == 100 + BAND_VARIANT_BASE + 4) return "conv_band_f16s3<96x128,6w>";
-    if (variant == 100 + BAND_VARIANT_BASE + 5) return "conv_band_f16s3<96x64,6w>";
+    if (variant >= 100 + BAND_VARIANT_BASE && variant < 100 + BAND_VARIANT_BASE + BAND_MODES) return conv_band_mode_info(variant - 100 - BAND_VARIANT_BASE).name;
     if (variant >= 100 && variant < 100 + HV_COUNT) return conv_f16s3_variant_info(variant - 100).name;
     if (variant < 0 || variant >= CV_COUNT) return "";
     return conv_variant_info(variant).name;

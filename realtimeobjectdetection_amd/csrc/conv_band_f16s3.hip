@@ -4,28 +4,36 @@
 // src/darknet.py:467-501, shortcut fused, 263-268).  The generic implicit-GEMM re-gathers every input
 // pixel once per tap: 9x the L2->CU traffic and 9x the LDS writes for the A operand (measured: 900 MB of
 // L1->L2 requests per launch for a 72 MB layer, ~1.3 ms of load stall over the 3x3 layers of YOLOv3).
-// Here a workgroup owns BM = 128 CONSECUTIVE output pixels (linear index over batch, y, x) and stages,
+// Here a workgroup owns BM CONSECUTIVE output pixels (linear index over batch, y, x) and stages,
 // once per 32-channel chunk, the band of input pixels those outputs can touch:
 //
-//     band row r  <->  input pixel (linear)  m0 - W - 1 + r,   r in [0, 128 + 2W + 2)
+//     band row r  <->  input pixel (linear)  m0 - W - 1 + r,   r in [0, BM + 2W + 2)
 //
 // so the A fragment of output row p for tap (ky,kx) is band row p + ky*W + kx: a constant shift per tap,
 // read straight from LDS (im2col never materialised).  Taps that fall outside the image (left/right edge,
 // top/bottom, other image of the batch) are redirected per lane to an all-zero LDS row by a 9-bit validity
-// mask computed once.  Consecutive pixels on consecutive lanes keep the 16-byte XOR swizzle conflict-free
-// for every shift.  K order is (channel chunk outer, tap inner): the weight planes are packed to match.
-// B (weights) is streamed per (chunk, tap) exactly like the generic kernel: double-buffered LDS, two
-// register stage sets, asm buffer loads with counted vmcnt.
+// mask computed once.  K order is (channel chunk outer, tap inner): the weight planes are packed to match.
+// B (weights) is streamed per (chunk, tap): double-buffered LDS, two register stage sets, asm buffer loads
+// with counted vmcnt.
 //
-// Limits: stride 1, pad 1, 3x3, Cin % 32 == 0, W <= 94 (band <= 320 rows = 40 KiB).
+// MFMA shape: v_mfma_f32_16x16x32_f16, one k32 step per 32-channel stage.  Against 32x32x16 it moves the same
+// LDS bytes per flop, but (a) the chip holds a higher clock on it (MI355X_MICROARCH 'DVFS give-back' (7);
+// measured here +3..5 % on the 76x76 / 38x38 layers) and (b) wave tiles are multiples of 16, not 32, which is
+// what makes the 192- and 96-row workgroup tiles below possible with 8 waves: the grid of a layer is a fixed
+// number of pixels, and 128-row tiles leave the 256 CUs 70 % filled on every YOLOv3 scale at batch 8
+// (722 / 364 / 184 tiles on 512 resident slots).  Each lane reads 16-byte chunk lane/16 of row lane%16; the
+// chunk swizzle (row >> 1) & 3 keeps that read conflict-free for EVERY band shift (tools/lds_bank_sim.py).
+//
+// A layer that this kernel supports always runs on it, at every batch size, whatever tile autotune picks:
+// all tiles accumulate a pixel's K products in the same order, so the frame-independence guarantee (bitwise
+// equal outputs for a frame whatever batch it rides in) holds although 16x16x32 and the generic kernel's
+// 32x32x16 round differently.
+//
+// Limits: stride 1, pad 1, 3x3, Cin % 32 == 0, W <= 94.
 #include "conv_f16s3_common.h"
 #include <cstdlib>
 
 namespace rtod {
-
-constexpr int BAND_ROWS = 320;                 // max band rows (128 + 2W + 2 <= 320)
-constexpr int BAND_ZERO = 320;                 // index of the all-zero row
-constexpr int BAND_PANEL = 336 * 64;           // bytes per plane (rows 321..335 unused padding)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 14 && N % 2 == 0, "vmcnt literal");
@@ -47,34 +55,41 @@ template <typename T, int N> __device__ __forceinline__ void tie_regs(T (&r)[N])
     else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) :: "memory");
 }
 
-// BM = output pixels per workgroup, NWM = waves along M (x 2 waves along N).
-//   BM 128, NWM 2: 4 waves of 64 x BN/2 (2 waves/SIMD)
-//   BM 128, NWM 4: 8 waves of 32 x BN/2 at 4 waves/SIMD — tools/ubench_tiles.hip: occupancy buys more MFMA
-//                  utilisation than a larger wave tile
-//   BM  96, NWM 3: 6 waves of 32 x BN/2 at 3 waves/SIMD — a tile height that fills whole rounds of the 512 resident
-//                  workgroup slots where 128 does not (38x38x8 x 512 ch: 484 tiles instead of 364)
-constexpr int band_min_waves(int nwm) { return nwm == 4 ? 4 : (nwm == 3 ? 3 : 2); }
+__device__ __forceinline__ int band_swz(int row) { return (row >> 1) & 3; }
 
-template <int BM, int BN, int NWM, int EPI>
-__global__ __launch_bounds__(NWM * 128, band_min_waves(NWM))
+constexpr int BAND_MAX_W = 94;
+constexpr int BAND_EPI_BYTES = 65536;          // the launch allocates at least this much LDS: the epilogue's transpose tile
+__host__ __device__ constexpr int band_rows(int bm, int w) { return (bm + 2 * w + 2 + 15) / 16 * 16; }   // zero row follows
+
+// BM x BN workgroup tile, NWM x NWN waves of (BM/NWM) x (BN/NWN); MINW = waves/SIMD the register budget must allow.
+//   128x128, 4x2: 8 waves of 32x64, 2 workgroups per CU (4 waves/SIMD) — tools/ubench_tiles.hip: occupancy buys more
+//                 MFMA utilisation than a larger wave tile
+//   192x128, 4x2 / 6x2: 8 waves of 48x64 or 12 of 32x64 — 76x76x8 pixels are 482 tiles instead of 722, 38x38x8 244
+//   96x128, 2x4: 8 waves of 48x32 — 19x19x8 pixels x 1024 channels are 248 tiles instead of 184
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI>
+__global__ __launch_bounds__(NWM * NWN * 64, MINW)
 void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
-    constexpr int WM = BM / NWM, WN = BN / 2, NT = NWM * 128;
-    static_assert(WM % 32 == 0 && BM + 2 * 94 + 2 <= BAND_ROWS + 64, "band tile");
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RPP = NT / 4;                               // rows per pass (4 x 16-B chunks per row)
+    constexpr int WM = BM / NWM, WN = BN / NWN, NT = NWM * NWN * 64;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int RPP = NT / 4;                               // rows per staging pass (4 x 16-B chunks per row)
     constexpr int B_SLOTS = (BN + RPP - 1) / RPP;
-    constexpr int BAND_SLOTS = (BAND_ROWS + RPP - 1) / RPP;   // 5 (4 waves) / 3 (8 waves)
-    static_assert(RPP % 16 == 0, "a pass that runs past a panel is predicated per 16-row wave slice");
+    constexpr int BAND_MAX = band_rows(BM, BAND_MAX_W);
+    constexpr int BAND_SLOTS = (BAND_MAX + RPP - 1) / RPP;
+    static_assert(RPP % 16 == 0, "a pass that runs past a panel is predicated per 16-row wave slice; swizzle period 8");
     constexpr int B_LOADS = 2 * B_SLOTS, BAND_LOADS = 2 * BAND_SLOTS;
+    static_assert(B_LOADS + BAND_LOADS <= 14 && 2 * B_LOADS <= 14, "vmcnt literals");
     constexpr int PANEL_B = BN * 64;
     constexpr int BSTAGE = 2 * PANEL_B;
-    constexpr int SMEM = 2 * BAND_PANEL + 2 * BSTAGE;
-    static_assert(SMEM >= WM * BN * 4, "one epilogue row group must fit");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned char* bandh = smem;
-    unsigned char* bandl = smem + BAND_PANEL;
-    unsigned char* bst = smem + 2 * BAND_PANEL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.Wi, H = a.Hi;
+    const int NBR = band_rows(BM, W);                          // band rows incl. padding; the zero row is row NBR
+    const int plane = (NBR + 1) * 64;
+    unsigned char* bst = smem;                                 // [2 stages][hi, lo][BN][64]
+    unsigned char* bandh = smem + 2 * BSTAGE;
+    unsigned char* bandl = bandh + plane;
+    const int zero_off = NBR * 64;
 
     const int nwg = grid_m * grid_n;
     int bid = blockIdx.x;
@@ -85,7 +100,6 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int bm = bid / grid_n, bn = bid - bm * grid_n;
 
     const int tid = threadIdx.x;
-    const int W = a.Wi, H = a.Hi;
     const int M = a.B * H * W;                                 // Ho == Hi, Wo == Wi
     const int m0 = bm * BM;
     const int NB = BM + 2 * W + 2;
@@ -94,7 +108,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const unsigned lo_plane = (unsigned)a.in_ldc * 2u;
 
     // zero row (both planes)
-    if (tid < 8) *reinterpret_cast<u32x4*>((tid < 4 ? bandh : bandl) + BAND_ZERO * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 8) *reinterpret_cast<u32x4*>((tid < 4 ? bandh : bandl) + zero_off + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- band loads: per-thread constant voffset, channel chunk through soffset
     unsigned bvo[BAND_SLOTS];
@@ -116,15 +130,15 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int n_cc = a.Cin / 32;
     const int nsteps = 9 * n_cc;
 
-    // ---- per-lane validity of the 9 taps for the two 32-row tiles this wave reads
+    // ---- per-lane validity of the 9 taps for the TM 16-row tiles this wave reads
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;                      // NWM x 2 waves
-    const int lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / NWN, wn = wave - wm * NWN;
+    const int lr = lane & 15, lh = lane >> 4;
     unsigned vmask[TM];
     int prow[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int p = wm * WM + i * 32 + lr;
+        const int p = wm * WM + i * 16 + lr;
         prow[i] = p;
         const int m = m0 + p;
         unsigned vm = 0;
@@ -184,7 +198,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         tie_regs(BRh); tie_regs(BRl);
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int wr_swz = (c16 ^ ((row0 >> 2) & 3)) << 4;
+    const int wr_swz = (c16 ^ band_swz(row0)) << 4;            // RPP % 8 == 0: the same for every pass
     auto write_b = [&](const BStage& S, int buf) {
         unsigned char* st = bst + buf * BSTAGE;
 #pragma unroll
@@ -200,63 +214,51 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #pragma unroll
         for (int j = 0; j < BAND_SLOTS; ++j) {
             const int o = (row0 + j * RPP) * 64 + wr_swz;
-            if ((j + 1) * RPP <= BAND_ROWS || row0 + j * RPP < BAND_ROWS) {     // never touch the zero row / padding
+            if (row0 + j * RPP < NBR) {                        // never touch the zero row
                 *reinterpret_cast<u32x4*>(bandh + o) = BRh[j];
                 *reinterpret_cast<u32x4*>(bandl + o) = BRl[j];
             }
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    const int rd_swz = (lr >> 2) & 3;
-    const int b_row = (wn * WN + lr) * 64;
-    // 4-wave blocks read the fragments of both k16 steps up front (64 VGPRs); 8-wave blocks must stay within
-    // 128 VGPRs for 4 waves/SIMD and read one k16 step at a time (the other waves of the SIMD cover the latency)
-    constexpr int FK = (NWM >= 3) ? 1 : 2;
-    struct Frags { f16x8 ah[FK][TM], al[FK][TM], bh[FK][TN], bl[FK][TN]; };
-    auto read_frags = [&](int tap, int buf, int ks0, Frags& F) {
+    const int b_lane = (wn * WN + lr) * 64 + ((lh ^ band_swz(lr)) << 4);     // WN % 16 == 0: the row's swizzle is the lane's
+    f16x8 ah[TM], al[TM];
+    auto read_a = [&](int tap) {
         const int shift = (tap / 3) * W + (tap % 3);
-        const unsigned char* st = bst + buf * BSTAGE;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = prow[i] + shift;
             const bool ok = (vmask[i] >> tap) & 1u;
-            const int swz = (row >> 2) & 3;
-#pragma unroll
-            for (int k = 0; k < FK; ++k) {
-                const int o = ok ? row * 64 + ((((ks0 + k) * 2 + lh) ^ swz) << 4) : BAND_ZERO * 64;
-                F.ah[k][i] = *reinterpret_cast<const f16x8*>(bandh + o);
-                F.al[k][i] = *reinterpret_cast<const f16x8*>(bandl + o);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < FK; ++k) {
-            const int co = (((ks0 + k) * 2 + lh) ^ rd_swz) << 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                F.bh[k][j] = *reinterpret_cast<const f16x8*>(st + b_row + j * 32 * 64 + co);
-                F.bl[k][j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + b_row + j * 32 * 64 + co);
-            }
+            const int o = ok ? row * 64 + ((lh ^ band_swz(row)) << 4) : zero_off;
+            ah[i] = *reinterpret_cast<const f16x8*>(bandh + o);
+            al[i] = *reinterpret_cast<const f16x8*>(bandl + o);
         }
     };
-    auto mfma_block = [&](const Frags& F) {
+    // per 16-column group: two B fragments, then 3 TM products (lo*hi, hi*lo, hi*hi: small terms first)
+    auto compute = [&](int buf) {
+        const unsigned char* st = bst + buf * BSTAGE + b_lane;
+        f16x8 bh[TN], bl[TN];
 #pragma unroll
-        for (int k = 0; k < FK; ++k)
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
+            bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
+        }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bl[k][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < TM; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
     };
 
     // ---- prologue.  Issue order (vmcnt is in-order): band(0), B0, B1 | band written, B0 staged | B2, band(1)
@@ -273,18 +275,16 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     band_age = 0;                                              // same issue pattern as at a chunk boundary: [B, B, band]
     __syncthreads();
 
-    Frags F;
     int tap = 0, cc = 0;
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
     auto step = [&](int buf, BStage& Snext) {
-        read_frags(tap, buf, 0, F);
+        read_a(tap);
         wait_b(Snext);
         write_b(Snext, buf ^ 1);
         gload_b(Snext);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block(F);
-        if constexpr (FK == 1) { read_frags(tap, buf, 1, F); mfma_block(F); }
+        compute(buf);
         __syncthreads();
         if (++tap == 9) {
             tap = 0; ++cc;
@@ -305,25 +305,48 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __syncthreads();
 
     if (a.dbg & 4) return;
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, SMEM>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, BAND_EPI_BYTES, 16, f32x4>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 }
 
-template <int BM, int BN, int NWM>
+template <int BM, int BN, int NWM, int NWN, int MINW>
 static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
-    if (a.res)
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BM, BN, NWM, EPI_SPLIT_RES>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
-    else
-        hipLaunchKernelGGL((conv_band_f16s3_kernel<BM, BN, NWM, EPI_SPLIT>), dim3(gm * gn), dim3(NWM * 128), 0, s, a, gm, gn);
+    const int main_bytes = 4 * BN * 64 + 2 * (band_rows(BM, a.Wi) + 1) * 64;
+    const int lds = main_bytes > BAND_EPI_BYTES ? main_bytes : BAND_EPI_BYTES;
+    auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES>;
+    auto k_plain = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT>;
+    static unsigned long long attr_done = 0;                   // per instantiation and device; > 64 KiB of dynamic LDS needs the opt-in
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_band_f16s3 hipGetDevice");
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        const int cap = 4 * BN * 64 + 2 * (band_rows(BM, BAND_MAX_W) + 1) * 64;
+        const int mx = cap > BAND_EPI_BYTES ? cap : BAND_EPI_BYTES;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+            return hip_fail(hipGetLastError(), "conv_band_f16s3 LDS attribute");
+        attr_done |= 1ull << (dev & 63);
+    }
+    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64), lds, s, a, gm, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64), lds, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_band_f16s3 launch");
 }
 
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
-    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && 128 + 2 * w_in + 2 <= BAND_ROWS;   // BM <= 128
+    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && w_in <= BAND_MAX_W;
 }
 
-// mode: 0 128x128/4w, 1 128x64/4w, 2 128x128/8w, 3 128x64/8w, 4 96x128/6w, 5 96x64/6w
+static const ConvVariantInfo kBandModes[BAND_MODES] = {
+    {128, 128, "conv_band_f16s3<128x128,4x2>"},
+    {128, 64, "conv_band_f16s3<128x64,4x2>"},
+    {192, 128, "conv_band_f16s3<192x128,4x2>"},
+    {192, 128, "conv_band_f16s3<192x128,6x2>"},
+    {96, 128, "conv_band_f16s3<96x128,2x4>"},
+    {128, 128, "conv_band_f16s3<128x128,2x2>"},
+    {64, 128, "conv_band_f16s3<64x128,2x4>"},
+};
+const ConvVariantInfo& conv_band_mode_info(int mode) { return kBandModes[mode < 0 || mode >= BAND_MODES ? 0 : mode]; }
+
 int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_band: null pointer"); return RTOD_E_ARG; }
@@ -337,12 +360,15 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (dbg_zero & 1) a.in_bytes = 1;
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
-    if (mode == 0) return launch_band<128, 128, 2>(a, s);
-    if (mode == 1) return launch_band<128, 64, 2>(a, s);
-    if (mode == 2) return launch_band<128, 128, 4>(a, s);
-    if (mode == 3) return launch_band<128, 64, 4>(a, s);
-    if (mode == 4) return launch_band<96, 128, 3>(a, s);
-    if (mode == 5) return launch_band<96, 64, 3>(a, s);
+    switch (mode) {
+        case 0: return launch_band<128, 128, 4, 2, 4>(a, s);
+        case 1: return launch_band<128, 64, 4, 2, 4>(a, s);
+        case 2: return launch_band<192, 128, 4, 2, 3>(a, s);
+        case 3: return launch_band<192, 128, 6, 2, 3>(a, s);
+        case 4: return launch_band<96, 128, 2, 4, 4>(a, s);
+        case 5: return launch_band<128, 128, 2, 2, 2>(a, s);
+        case 6: return launch_band<64, 128, 2, 4, 4>(a, s);
+    }
     set_error("launch_conv_band: mode %d unsupported", mode);
     return RTOD_E_ARG;
 }

@@ -49,10 +49,13 @@ constexpr int epi_row_group(int bm, int wm, int rg_max) {
 
 // ---- common epilogue: scale / bias / leaky, LDS transpose, then split-format store (+ residual) or head decode.
 // `smem` is the kernel's whole LDS allocation (dead after the main loop, which must end on a barrier).
-template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES>
-__device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x16 (&acc)[WM / 32][WN / 32], unsigned char* smem,
+// MT = MFMA tile edge: 32 (v_mfma_f32_32x32x16_f16: lane holds column lane%32, rows (e&3) + 8(e>>2) + 4(lane/32)) or
+// 16 (v_mfma_f32_16x16x32_f16: column lane%16, rows e + 4(lane/16)).
+template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int MT = 32, typename AccT = f32x16>
+__device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&acc)[WM / MT][WN / MT], unsigned char* smem,
                                                     int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M) {
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TM = WM / MT, TN = WN / MT, NE = MT * MT / 64;
+    static_assert(sizeof(AccT) == NE * 4, "accumulator type / MFMA tile");
     // ---- epilogue.  The accumulators (MFMA layout: channel on the lane, 16 pixel rows per register set)
     // are scaled / biased / activated and transposed through LDS (the stage buffers are dead: the main
     // loop ended on a barrier) as an fp32 [rows][BN] tile, so that the residual loads and the output
@@ -68,15 +71,15 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x16 (&
         if (wm * WM >= rg && wm * WM < rg + RG) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int nl = wn * WN + j * 32 + lr;
+                const int nl = wn * WN + j * MT + lr;
                 const int n = bn * BN + nl;
                 const float bias = (n < a.Cout ? a.bias[n] : 0.f) * escale;
                 const float inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = wm * WM - rg + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    for (int e = 0; e < NE; ++e) {
+                        const int rl = wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh;
                         float v = acc[i][j][e] * inv + bias;
                         if (a.leaky) v = v > 0.f ? v : v * 0.1f;
                         T[rl * BN + nl] = v;

@@ -697,13 +697,16 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     hipEvent_t e0, e1;
     RTOD_HIP(hipEventCreate(&e0)); RTOD_HIP(hipEventCreate(&e1));
     std::vector<int> cand;
-    for (int v = 0; v < HV_COUNT; ++v) {
-        const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
-        if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;           // tile far wider than the layer
-        cand.push_back(v);
+    if (convs[l.conv_slot].band) {                                                    // band layers: band tiles only (see rtod_internal.h)
+        for (int m = 0; m < BAND_MODES; ++m) cand.push_back(BAND_VARIANT_BASE + m);
+    } else {
+        for (int v = 0; v < HV_COUNT; ++v) {
+            const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
+            if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
+            cand.push_back(v);
+        }
     }
-    if (convs[l.conv_slot].band) for (int m = 0; m < 6; ++m) cand.push_back(BAND_VARIANT_BASE + m);
-    int best_v = choose_variant_f16s3(L, batch);
+    int best_v = variant_for(l, batch);
     int rc = RTOD_OK;
     // min over `reps` timed groups of `per` back-to-back launches
     auto time_variant = [&](int v, int reps, int per, float& out_ms) -> int {
@@ -747,13 +750,16 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
 
 int Plan::variant_for(const Launch& l, int batch) const {
     const char* force = getenv("RTOD_F16S3_VARIANT");
-    if (force && *force && atoi(force) >= BAND_VARIANT_BASE && convs[l.conv_slot].band) return atoi(force);
-    if (!(force && *force)) {
-        auto it = tuned.find(batch);
-        const size_t idx = &l - &launches[0];
-        if (it != tuned.end() && idx < it->second.size() && it->second[idx] >= 0) return it->second[idx];
+    const bool band = convs[l.conv_slot].band;
+    if (force && *force) {                                   // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
+        const int v = atoi(force);
+        if (band) return v >= BAND_VARIANT_BASE && v < BAND_VARIANT_BASE + BAND_MODES ? v : BAND_VARIANT_BASE;
+        return choose_variant_f16s3(layers[l.layer], batch);
     }
-    return choose_variant_f16s3(layers[l.layer], batch);
+    auto it = tuned.find(batch);
+    const size_t idx = &l - &launches[0];
+    if (it != tuned.end() && idx < it->second.size() && it->second[idx] >= 0) return it->second[idx];
+    return band ? BAND_VARIANT_BASE : choose_variant_f16s3(layers[l.layer], batch);
 }
 
 int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
@@ -772,7 +778,8 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
     if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
     if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
     RTOD_HIP(hipSetDevice(device));
-    const bool tune_now = precision == 1 && !tuned.count(batch) && !getenv("RTOD_NO_AUTOTUNE");   // first forward of a batch size
+    const char* forced = getenv("RTOD_F16S3_VARIANT");
+    const bool tune_now = precision == 1 && !tuned.count(batch) && !getenv("RTOD_NO_AUTOTUNE") && !(forced && *forced);   // first forward of a batch size
     if (tune_now) { tuning.assign(launches.size(), -1); tune_cache.clear(); }
     const size_t nl = launches.size();
     if (launch_ms && events.size() < 2 * nl) {

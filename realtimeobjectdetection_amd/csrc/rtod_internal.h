@@ -78,8 +78,12 @@ const ConvVariantInfo& conv_f16s3_variant_info(int v);
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 // 3x3 stride-1 pad-1 convs with an LDS-resident input band (conv_band_f16s3.hip); weights in band K order
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
+// A layer the band kernel supports ALWAYS runs on it (16x16x32 MFMA; the generic kernel's 32x32x16 rounds differently, and
+// a frame's output must not depend on the batch it rides in); autotune only picks the tile.
+constexpr int BAND_MODES = 7;              // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4
+const ConvVariantInfo& conv_band_mode_info(int mode);
 int launch_conv_band_f16s3(const ConvArgs& a, int mode, hipStream_t s);
-constexpr int BAND_VARIANT_BASE = 50;      // tuned-variant ids >= this select the band kernel: +0 128x128/4 waves, +1 128x64/4w, +2 128x128/8w, +3 128x64/8w, +4 96x128/6w, +5 96x64/6w
+constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the band kernel: BAND_VARIANT_BASE + mode
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
