@@ -103,11 +103,19 @@ def rocprof_kernel_name(tile_name, epi):
         bm, bn, nwm, nwn = [int(v) for v in mb.groups()]
         minw = {(192, 128): 3, (128, 128): 4 if nwm == 4 else 2}.get((bm, bn), 4)     # launch_conv_band_f16s3's MINW per mode
         return "void rtod::conv_band_f16s3_kernel<%d, %d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, nwm, nwn, minw, epi)
-    m = re.match(r"conv_igemm_(f16s3|f32)<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
-    kind, bm, bn, wm, wn = m.group(1), *[int(v) for v in m.groups()[1:]]
-    if kind == "f16s3":
-        return "void rtod::conv_igemm_f16s3_kernel<%d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, wm, wn, epi)
+    mh = re.match(r"conv_igemm_f16s3<(\d+)x(\d+),(\d)x(\d)>", tile_name)
+    if mh:
+        bm, bn, nwm, nwn = [int(v) for v in mh.groups()]
+        minw = IGEMM_MINW[(bm, bn, nwm, nwn)]
+        return "void rtod::conv_igemm_f16s3_kernel<%d, %d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, nwm, nwn, minw, epi)
+    m = re.match(r"conv_igemm_f32<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
+    bm, bn, wm, wn = [int(v) for v in m.groups()]
     return "void rtod::conv_igemm_f32_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, wm, wn)
+
+
+# launch_conv_f16s3's MINW template argument per tile (conv_igemm_f16s3.hip)
+IGEMM_MINW = {(128, 128, 2, 2): 2, (128, 64, 2, 2): 3, (64, 64, 2, 2): 4, (64, 128, 2, 2): 3, (256, 128, 4, 2): 2, (128, 256, 2, 4): 2,
+              (128, 128, 4, 2): 4, (128, 64, 4, 2): 4, (256, 128, 8, 2): 4, (192, 128, 4, 2): 3, (96, 128, 2, 4): 4, (192, 128, 6, 2): 3}
 
 
 def roofline_from_launches(model, x, steps):

@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution on split-precision f16 MFMA (v_mfma_f32_32x32x16_f16), gfx950.
+// Implicit-GEMM convolution on split-precision f16 MFMA (v_mfma_f32_16x16x32_f16), gfx950.
 //
 // Same contract, GEMM view and epilogues as conv_igemm_f32.hip (reference: conv -> BN(eval) -> leaky,
 // src/darknet.py:467-501; shortcut 263-268; head decode src/util.py:193-237), but the contraction
@@ -16,9 +16,11 @@
 // Weights: [Npad][Kpad] hi and lo planes, per-output-channel power-of-two pre-scale undone (exactly)
 // in the epilogue through inv_scale[n].
 //
-// Main loop: BMxBNx32 per stage; LDS double-buffered, four 64-byte-row f16 panels per stage with a
-// 16-byte-chunk XOR swizzle (chunk ^= (row>>2)&3: conflict-free ds_read_b128 / ds_write_b128);
-// two register stage sets keep two K-chunks of global loads in flight; one barrier per K-chunk.
+// Main loop: BMxBNx32 per stage = one k32 step of 16x16x32 MFMAs (the shape the chip clocks highest on, and
+// whose 16-row granularity allows 48-row wave tiles: conv_band_f16s3.hip); LDS double-buffered, four
+// 64-byte-row f16 panels per stage with a 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&3: conflict-free
+// ds_read_b128 for 16 rows x 4 chunks per read, tools/lds_bank_sim.py); two register stage sets keep two
+// K-chunks of global loads in flight; one barrier per K-chunk.
 // K order: k = ((c/32)*kh*kw + tap)*32 + c%32 (channel chunk outer, tap inner).
 // Addressing: the tap (ky,kx) and channel offset of a K-chunk are wave-uniform (Cin % 32 == 0) and
 // advanced in scalar registers; loads are raw buffer loads whose per-lane voffset is
@@ -33,20 +35,19 @@ struct StageRegs {
     u32x4 ah[ASL], al[ASL], bh[BSL], bl[BSL];
 };
 
-// Waves per SIMD the register budget must admit (2nd __launch_bounds__ argument): wave tiles of 32x64 or smaller
-// (<= 32 accumulator registers) are built for 4 waves/SIMD — tools/ubench_tiles.hip: occupancy buys more MFMA
-// utilisation than a larger wave tile — the 64x64 wave tiles need ~220 registers and run at 2.
-constexpr int igemm_min_waves(int wm, int wn) { return (wm / 32) * (wn / 32) <= 2 ? 4 : 2; }
-
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, igemm_min_waves(WM, WN))
+// BM x BN workgroup tile, NWM x NWN waves of (BM/NWM) x (BN/NWN), both multiples of 16.  MINW = waves per SIMD the
+// register budget must admit (2nd __launch_bounds__ argument): wave tiles of 32x64 / 48x32 or smaller are built for
+// 4 waves/SIMD — tools/ubench_tiles.hip: occupancy buys more MFMA utilisation than a larger wave tile.
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI>
+__global__ __launch_bounds__(NWM * NWN * 64, MINW)
 void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
-    constexpr int NWN = BN / WN;
-    constexpr int NT = (BM / WM) * NWN * 64;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int NT = NWM * NWN * 64;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
+    constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int RPP = NT / 4;                    // rows per pass: 4 x 16-B chunks per 64-B row
     constexpr int A_SLOTS = (BM + RPP - 1) / RPP, B_SLOTS = (BN + RPP - 1) / RPP;
-    static_assert(RPP % 16 == 0, "swizzle needs rows-per-pass % 16 == 0");
+    static_assert(RPP % 16 == 0, "predication per 16-row wave slice; swizzle period 8");
     // a pass that runs past the panel (BM or BN not a multiple of RPP) is predicated per 16-row wave
     // slice: its loads are issued out of range (the vmcnt count per stage stays constant) and its LDS
     // writes are skipped
@@ -126,6 +127,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         if (++ld_kx == a.kw) { ld_kx = 0; if (++ld_ky == a.kh) { ld_ky = 0; ld_c0 += HBK; } }
     };
     constexpr int LOADS_PER_STAGE = 2 * A_SLOTS + 2 * B_SLOTS;
+    static_assert(LOADS_PER_STAGE <= 8, "vmcnt literals below");
     // wait until at most `LOADS_PER_STAGE` loads (the younger stage set) are outstanding: the older set S
     // has landed.  Every register of S is an in/out operand so no use can be scheduled above the wait.
     auto wait_stage = [&](StageRegs<A_SLOTS, B_SLOTS>& S) {
@@ -143,8 +145,8 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.ah[0]), "+v"(S.al[0]), "+v"(S.bh[0]), "+v"(S.bl[0]) :: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // LDS image: panel row r, 16-B chunk c at byte r*64 + ((c ^ ((r>>2)&3)) << 4)
-    const int wr_swz = (c16 ^ ((row0 >> 2) & 3)) << 4;           // RPP % 16 == 0 -> same swizzle for every slot
+    // LDS image: panel row r, 16-B chunk c at byte r*64 + ((c ^ ((r>>1)&3)) << 4)
+    const int wr_swz = (c16 ^ ((row0 >> 1) & 3)) << 4;           // RPP % 8 == 0 -> same swizzle for every slot
     auto lds_write = [&](const StageRegs<A_SLOTS, B_SLOTS>& S, int buf) {
         unsigned char* st = smem + buf * STAGE;
 #pragma unroll
@@ -165,54 +167,49 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / NWN, wn = wave - wm * NWN;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int rd_swz = (lr >> 2) & 3;
-    const int a_row = (wm * WM + lr) * 64, b_row = (wn * WN + lr) * 64;
+    const int lr = lane & 15, lh = lane >> 4;
+    const int co = (lh ^ ((lr >> 1) & 3)) << 4;                  // WM, WN % 16 == 0: the row's swizzle is the lane's
+    const int a_row = (wm * WM + lr) * 64 + co, b_row = 2 * PANEL_A + (wn * WN + lr) * 64 + co;
 
-    // fragments of one whole K-chunk (both k16 steps) are read into registers first, then the next
-    // chunk's LDS writes and the global loads of the chunk after are issued, and only then the 24-MFMA
-    // block runs: the LDS write drain (~80 B/clk/CU through the VGPR path) and the load latency overlap
-    // with the matrix pipe instead of sitting between the MFMAs and the barrier.
-    constexpr int FK = igemm_min_waves(WM, WN) == 4 ? 1 : 2;       // k16 steps of fragments held at once
-    struct Frags { f16x8 ah[FK][TM], al[FK][TM], bh[FK][TN], bl[FK][TN]; };
-    auto read_frags = [&](int buf, int ks0, Frags& F) {
-        const unsigned char* st = smem + buf * STAGE;
+    // the A fragments of the K-chunk are read into registers first, then the next chunk's LDS writes and the
+    // global loads of the chunk after are issued, and only then the MFMA block runs (B fragments read per
+    // 16-column group just ahead of their MFMAs): the LDS write drain (~80 B/clk/CU through the VGPR path) and
+    // the load latency overlap with the matrix pipe instead of sitting between the MFMAs and the barrier.
+    f16x8 ah[TM], al[TM];
+    auto read_a = [&](int buf) {
+        const unsigned char* st = smem + buf * STAGE + a_row;
 #pragma unroll
-        for (int k = 0; k < FK; ++k) {
-            const int co = (((ks0 + k) * 2 + lh) ^ rd_swz) << 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                F.ah[k][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 64 + co);
-                F.al[k][i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + a_row + i * 32 * 64 + co);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                F.bh[k][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + b_row + j * 32 * 64 + co);
-                F.bl[k][j] = *reinterpret_cast<const f16x8*>(st + 2 * PANEL_A + PANEL_B + b_row + j * 32 * 64 + co);
-            }
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(st + i * 16 * 64);
+            al[i] = *reinterpret_cast<const f16x8*>(st + PANEL_A + i * 16 * 64);
         }
     };
-    auto mfma_block = [&](const Frags& F) {
+    auto compute = [&](int buf) {
+        const unsigned char* st = smem + buf * STAGE + b_row;
+        f16x8 bh[TN], bl[TN];
 #pragma unroll
-        for (int k = 0; k < FK; ++k)
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
+            bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
+        }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bl[k][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[k][i], F.bh[k][j], acc[i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < TM; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
     };
 
     // prologue: chunks 0 and 1 in flight, chunk 0 staged, chunk 2 issued.  The steady state is
@@ -226,56 +223,56 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     lds_write(S0, 0);
     gload(S0);
     __syncthreads();
-    Frags F;
     for (int t = 0; t < nk; t += 2) {
-        read_frags(0, 0, F);                          // chunk t
+        read_a(0);                                    // chunk t
         wait_stage(S1);
         lds_write(S1, 1);                             // chunk t+1
         gload(S1);                                    // chunk t+3
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block(F);
-        if constexpr (FK == 1) { read_frags(0, 1, F); mfma_block(F); }
+        compute(0);
         __syncthreads();
-        read_frags(1, 0, F);                          // chunk t+1
+        read_a(1);                                    // chunk t+1
         wait_stage(S0);
         lds_write(S0, 0);                             // chunk t+2
         gload(S0);                                    // chunk t+4
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block(F);
-        if constexpr (FK == 1) { read_frags(1, 1, F); mfma_block(F); }
+        compute(1);
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
 
     if (a.dbg & 4) return;                            // timing experiment: no epilogue
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE, 16, f32x4>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 }
 
 static const ConvVariantInfo kHVariants[HV_COUNT] = {
-    {128, 128, "conv_igemm_f16s3<128x128,w64x64>"},
-    {128, 64, "conv_igemm_f16s3<128x64,w64x32>"},
-    {64, 64, "conv_igemm_f16s3<64x64,w32x32>"},
-    {64, 128, "conv_igemm_f16s3<64x128,w32x64>"},
-    {256, 128, "conv_igemm_f16s3<256x128,w64x64>"},
-    {128, 256, "conv_igemm_f16s3<128x256,w64x64>"},
-    {128, 128, "conv_igemm_f16s3<128x128,w32x64>"},
-    {128, 64, "conv_igemm_f16s3<128x64,w32x32>"},
-    {256, 128, "conv_igemm_f16s3<256x128,w32x64>"},
+    {128, 128, "conv_igemm_f16s3<128x128,2x2>"},
+    {128, 64, "conv_igemm_f16s3<128x64,2x2>"},
+    {64, 64, "conv_igemm_f16s3<64x64,2x2>"},
+    {64, 128, "conv_igemm_f16s3<64x128,2x2>"},
+    {256, 128, "conv_igemm_f16s3<256x128,4x2>"},
+    {128, 256, "conv_igemm_f16s3<128x256,2x4>"},
+    {128, 128, "conv_igemm_f16s3<128x128,4x2>"},
+    {128, 64, "conv_igemm_f16s3<128x64,4x2>"},
+    {256, 128, "conv_igemm_f16s3<256x128,8x2>"},
+    {192, 128, "conv_igemm_f16s3<192x128,4x2>"},
+    {96, 128, "conv_igemm_f16s3<96x128,2x4>"},
+    {192, 128, "conv_igemm_f16s3<192x128,6x2>"},
 };
 
 const ConvVariantInfo& conv_f16s3_variant_info(int v) { return kHVariants[v < 0 || v >= HV_COUNT ? 0 : v]; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int NWM, int NWN, int MINW>
 static int launch_h(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    if (a.dec.enabled)
-        hipLaunchKernelGGL((conv_igemm_f16s3_kernel<BM, BN, WM, WN, EPI_DECODE>), dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
-    else if (a.res)
-        hipLaunchKernelGGL((conv_igemm_f16s3_kernel<BM, BN, WM, WN, EPI_SPLIT_RES>), dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
-    else
-        hipLaunchKernelGGL((conv_igemm_f16s3_kernel<BM, BN, WM, WN, EPI_SPLIT>), dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
+    constexpr int NT = NWM * NWN * 64;
+    auto k_dec = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_DECODE>;
+    auto k_res = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES>;
+    auto k_plain = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT>;
+    if (a.dec.enabled) hipLaunchKernelGGL(k_dec, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
+    else if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_igemm_f16s3 launch");
 }
 
@@ -298,15 +295,18 @@ int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
     switch (variant) {
-        case HV_128x128: return launch_h<128, 128, 64, 64>(a, s);
-        case HV_128x64: return launch_h<128, 64, 64, 32>(a, s);
-        case HV_64x64: return launch_h<64, 64, 32, 32>(a, s);
-        case HV_64x128: return launch_h<64, 128, 32, 64>(a, s);
-        case HV_256x128: return launch_h<256, 128, 64, 64>(a, s);
-        case HV_128x256: return launch_h<128, 256, 64, 64>(a, s);
-        case HV_128x128_8W: return launch_h<128, 128, 32, 64>(a, s);
-        case HV_128x64_8W: return launch_h<128, 64, 32, 32>(a, s);
-        case HV_256x128_16W: return launch_h<256, 128, 32, 64>(a, s);
+        case HV_128x128: return launch_h<128, 128, 2, 2, 2>(a, s);
+        case HV_128x64: return launch_h<128, 64, 2, 2, 3>(a, s);
+        case HV_64x64: return launch_h<64, 64, 2, 2, 4>(a, s);
+        case HV_64x128: return launch_h<64, 128, 2, 2, 3>(a, s);
+        case HV_256x128: return launch_h<256, 128, 4, 2, 2>(a, s);
+        case HV_128x256: return launch_h<128, 256, 2, 4, 2>(a, s);
+        case HV_128x128_8W: return launch_h<128, 128, 4, 2, 4>(a, s);
+        case HV_128x64_8W: return launch_h<128, 64, 4, 2, 4>(a, s);
+        case HV_256x128_16W: return launch_h<256, 128, 8, 2, 4>(a, s);
+        case HV_192x128_8W: return launch_h<192, 128, 4, 2, 3>(a, s);
+        case HV_96x128_8W: return launch_h<96, 128, 2, 4, 4>(a, s);
+        case HV_192x128_12W: return launch_h<192, 128, 6, 2, 3>(a, s);
     }
     set_error("launch_conv_f16s3: unknown variant %d", variant);
     return RTOD_E_ARG;

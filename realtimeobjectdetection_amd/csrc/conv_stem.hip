@@ -90,8 +90,9 @@ void conv_stem_kernel(const StemArgs a) {
                             ph[e] = h; pl[e] = (_Float16)(v - (float)h);
                         }
                         _Float16* o = reinterpret_cast<_Float16*>(a.out) + (int64_t)mo * 2 * a.out_ldc + a.out_coff + ct * 32 + c8;
-                        *reinterpret_cast<f16x8s*>(o) = ph;
-                        *reinterpret_cast<f16x8s*>(o + a.out_ldc) = pl;
+                        // sc1 write-through stores: see conv_f16s3_common.h store_act16
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o), "v"(ph) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o + a.out_ldc), "v"(pl) : "memory");
                     } else {
                         float* o = a.out + (int64_t)mo * a.out_ldc + a.out_coff + ct * 32 + c8;
                         *reinterpret_cast<f32x4*>(o) = v0;

@@ -73,7 +73,8 @@ enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, C
 struct ConvVariantInfo { int bm, bn; const char* name; };
 const ConvVariantInfo& conv_variant_info(int v);
 int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
-enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_256x128 = 4, HV_128x256 = 5, HV_128x128_8W = 6, HV_128x64_8W = 7, HV_256x128_16W = 8, HV_COUNT };
+enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_256x128 = 4, HV_128x256 = 5, HV_128x128_8W = 6, HV_128x64_8W = 7, HV_256x128_16W = 8,
+                      HV_192x128_8W = 9, HV_96x128_8W = 10, HV_192x128_12W = 11, HV_COUNT };
 const ConvVariantInfo& conv_f16s3_variant_info(int v);
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 // 3x3 stride-1 pad-1 convs with an LDS-resident input band (conv_band_f16s3.hip); weights in band K order
