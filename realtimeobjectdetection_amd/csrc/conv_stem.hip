@@ -39,16 +39,16 @@ void conv_stem_kernel(const StemArgs a) {
 #pragma unroll
         for (int s = 0; s < 14; ++s) wreg[s] = a.w[(2 * s + lh) * a.Cout + ct * 32 + lr];
         const float bias = a.bias[ct * 32 + lr];
-        for (int tile = blockIdx.x * 4 + wave; tile * 32 < M; tile += gridDim.x * 4) {
+        const int hw = a.Ho * a.Wo;
+        // gather of one tile's A operand (14 dwords per lane); issued one tile ahead of its MFMAs
+        auto gather = [&](int tile, float (&av)[14]) {
             const int m = tile * 32 + lr;
             const bool mok = m < M;
             const int mm = mok ? m : 0;
-            const int hw = a.Ho * a.Wo;
             const int b = mm / hw, r = mm - b * hw;
             const int oy = r / a.Wo, ox = r - oy * a.Wo;
             const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
             const float* xb = a.x + (int64_t)b * 3 * plane;
-            float av[14];
 #pragma unroll
             for (int s = 0; s < 14; ++s) {
                 const int k = 2 * s + lh;                       // 0..27
@@ -58,6 +58,13 @@ void conv_stem_kernel(const StemArgs a) {
                 const bool ok = mok && k < 27 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 av[s] = ok ? xb[c * plane + (int64_t)iy * a.W + ix] : 0.f;
             }
+        };
+        const int tstep = gridDim.x * 4;
+        int tile = blockIdx.x * 4 + wave;
+        float av[14], an[14];
+        if (tile * 32 < M) gather(tile, av);
+        for (; tile * 32 < M; tile += tstep) {
+            if ((tile + tstep) * 32 < M) gather(tile + tstep, an);          // wave-uniform
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -72,28 +79,39 @@ void conv_stem_kernel(const StemArgs a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the wave's own LDS writes, then reads (in order)
             __builtin_amdgcn_wave_barrier();
-            // 32 pixels x 4 groups of 8 channels = 128 groups, two per lane
+            if (a.out_split) {
+                // 32 pixels x 8 pieces of 16 bytes (4 hi chunks, 4 lo chunks of 8 channels), four per lane.  With
+                // out_ldc == 32 a pixel is 128 contiguous bytes [hi 64][lo 64]: every store instruction of the wave
+                // writes 1 KiB contiguously.  sc1 write-through stores: see conv_f16s3_common.h store_act16.
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int g = lane + q * 64;
-                const int p = g >> 2, c8 = (g & 3) * 8;
-                const int mo = tile * 32 + p;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8 + 4);
-                if (mo < M) {
-                    if (a.out_split) {
-                        f16x8s ph, pl;
+                for (int q = 0; q < 4; ++q) {
+                    const int g = lane + q * 64;
+                    const int p = g >> 3, j = g & 7, c8 = (j & 3) * 8;
+                    const int mo = tile * 32 + p;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8 + 4);
+                    f16x8s pk;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float v = (e < 4 ? v0[e] : v1[e - 4]) * SPLIT_SCALE;
-                            const _Float16 h = (_Float16)v;
-                            ph[e] = h; pl[e] = (_Float16)(v - (float)h);
-                        }
-                        _Float16* o = reinterpret_cast<_Float16*>(a.out) + (int64_t)mo * 2 * a.out_ldc + a.out_coff + ct * 32 + c8;
-                        // sc1 write-through stores: see conv_f16s3_common.h store_act16
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o), "v"(ph) : "memory");
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o + a.out_ldc), "v"(pl) : "memory");
-                    } else {
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (e < 4 ? v0[e] : v1[e - 4]) * SPLIT_SCALE;
+                        const _Float16 h = (_Float16)v;
+                        pk[e] = j < 4 ? h : (_Float16)(v - (float)h);
+                    }
+                    if (mo < M) {
+                        _Float16* o = reinterpret_cast<_Float16*>(a.out) + (int64_t)mo * 2 * a.out_ldc + a.out_coff + ct * 32 + c8 + (j < 4 ? 0 : a.out_ldc);
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o), "v"(pk) : "memory");
+                    }
+                }
+            } else {
+                // 32 pixels x 4 groups of 8 channels = 128 groups, two per lane
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = lane + q * 64;
+                    const int p = g >> 2, c8 = (g & 3) * 8;
+                    const int mo = tile * 32 + p;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tw + p * 36 + c8 + 4);
+                    if (mo < M) {
                         float* o = a.out + (int64_t)mo * a.out_ldc + a.out_coff + ct * 32 + c8;
                         *reinterpret_cast<f32x4*>(o) = v0;
                         *reinterpret_cast<f32x4*>(o + 4) = v1;
@@ -102,6 +120,8 @@ void conv_stem_kernel(const StemArgs a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 14; ++s) av[s] = an[s];
         }
     }
 }
