@@ -457,7 +457,12 @@ void Plan::layout_weights() {
         const Layer& L = layers[pc.layer];
         pc.split = uses_split(L, pc.cin_p);
         const int64_t panel = (int64_t)pc.Npad * pc.Kpad;
-        if (pc.stem) {
+        if (pc.stem && precision == 1) {                              // split stem: [Cout][32] f16 hi, lo, inv_scale
+            pc.split = true;
+            pc.w_off = packed_floats; packed_floats += 16 * (int64_t)L.cout;
+            pc.wl_off = packed_floats; packed_floats += 16 * (int64_t)L.cout;
+            pc.s_off = packed_floats; packed_floats += L.cout;
+        } else if (pc.stem) {
             pc.w_off = packed_floats; packed_floats += 28 * (int64_t)L.cout;
         } else if (pc.split) {
             pc.w_off = packed_floats; packed_floats += panel / 2;       // f16 hi plane
@@ -572,7 +577,32 @@ int Plan::load_weights(const float* w, size_t n) {
             for (int o = 0; o < C; ++o) bias[o] = p[o];
             p += C;
         }
-        if (pc.stem) {
+        if (pc.stem && pc.split) {
+            // [Cout][32] f16 hi / lo planes, k = (ky*3+kx)*3 + c, k >= 27 zero; per-channel power-of-two pre-scale as below
+            uint16_t* wh = reinterpret_cast<uint16_t*>(packed.data() + pc.w_off);
+            uint16_t* wl = reinterpret_cast<uint16_t*>(packed.data() + pc.wl_off);
+            float* inv = packed.data() + pc.s_off;
+            const int64_t per_o = (int64_t)cin * k * k;
+            for (int o = 0; o < C; ++o) {
+                double mx = 0.0;
+                for (int64_t q = 0; q < per_o; ++q) mx = std::max(mx, std::fabs((double)p[o * per_o + q] * scale[o]));
+                int e = 0;
+                if (mx > 0.0) { int ex; std::frexp(mx, &ex); e = 13 - ex; }
+                e = std::max(-24, std::min(40, e));
+                const double ps = std::ldexp(1.0, e);
+                inv[o] = (float)(std::ldexp(1.0, -e) / (double)ACT_SCALE_F16S3);
+                for (int q = 0; q < 32; ++q) { wh[o * 32 + q] = 0; wl[o * 32 + q] = 0; }
+                for (int c = 0; c < cin; ++c)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const float v = (float)((double)p[(((int64_t)o * cin + c) * k + ky) * k + kx] * scale[o]);
+                            const float vs = (float)((double)v * ps);
+                            const uint16_t h = f32_to_f16_rn(vs);
+                            const int idx = o * 32 + (ky * k + kx) * 3 + c;
+                            wh[idx] = h; wl[idx] = f32_to_f16_rn(vs - f16_to_f32(h));
+                        }
+            }
+        } else if (pc.stem) {
             float* wp = packed.data() + pc.w_off;                 // [28][Cout], k = (ky*3+kx)*3 + c
             for (int o = 0; o < C; ++o)
                 for (int c = 0; c < cin; ++c)
@@ -812,8 +842,13 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 const Layer& L = layers[l.layer];
                 const PackedConv& pc = convs[l.conv_slot];
                 const View o = view_of(l.out_layer);
-                rc = launch_conv_stem(x, d_weights + pc.w_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
-                                      L.stride, L.cout, L.leaky ? 1 : 0, s);
+                if (pc.split)
+                    rc = launch_conv_stem_split(x, reinterpret_cast<const _Float16*>(d_weights + pc.w_off), reinterpret_cast<const _Float16*>(d_weights + pc.wl_off),
+                                                d_weights + pc.s_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
+                                                L.stride, L.cout, L.leaky ? 1 : 0, s);
+                else
+                    rc = launch_conv_stem(x, d_weights + pc.w_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
+                                          L.stride, L.cout, L.leaky ? 1 : 0, s);
                 break;
             }
             case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;

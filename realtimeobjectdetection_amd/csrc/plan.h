@@ -53,7 +53,7 @@ struct PackedConv {
     int layer = 0;
     int cin_p = 0, K = 0, Kpad = 0, Npad = 0;
     int64_t w_off = 0, b_off = 0;     // float offsets into the device weight arena
-    bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32
+    bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32, or (split) [Cout][32] f16 hi / lo planes + inv_scale
     bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
     bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale

@@ -88,6 +88,8 @@ constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the ban
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
+int launch_conv_stem_split(const float* x_nchw, const _Float16* wh, const _Float16* wl, const float* inv_scale, const float* bias,
+                           const View& out, int B, int H, int W, int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
 int launch_prep_image(const unsigned char* img, int h, int w, int bgr, int inp_dim, float* out, hipStream_t s);
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
