@@ -132,11 +132,11 @@ def roofline_from_launches(model, x, steps):
     lib = _ffi.lib()
     groups = {}
     for li, ms in zip(infos, tot):
-        if li.kind != 0:
+        if li.kind != 0 or li.flops_per_frame == 0:      # non-conv launches; 1x1 convs fused into the previous conv's epilogue
             continue
         # group by the exact kernel instantiation rocprofv3 reports (tile variant + epilogue)
         name = lib.rtod_conv_variant_name(li.variant).decode()
-        epi = 2 if li.fused_decode else (1 if li.fused_residual else 0)
+        epi = 2 if li.fused_decode else ((4 if li.fused_residual else 3) if li.fused_pointwise else (1 if li.fused_residual else 0))
         kname = rocprof_kernel_name(name, epi)
         g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "tile": name})
         g["ms"] += float(ms); g["flops"] += float(li.flops_per_frame) * B; g["launches"] += 1

@@ -56,6 +56,7 @@ typedef struct rtod_launch_info {
     int32_t variant;           /* conv tile variant id (see rtod_conv_variant_name) */
     int32_t ksize, stride, cin, cout, hout, wout;
     int32_t fused_residual, fused_decode;
+    int32_t fused_pointwise;   /* 1: the next layer's 1x1 conv runs in this conv's epilogue (its own launch entry is then empty) */
     int64_t flops_per_frame;   /* algorithmic 2*MACs (0 for non-conv launches) */
     int64_t bytes_per_frame;   /* algorithmic bytes: input once + output once (+ residual) */
     int64_t weight_bytes;      /* read once per launch */

@@ -28,7 +28,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("layer", C.c_int32), ("kind", C.c_int32), ("variant", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("hout", C.c_int32), ("wout", C.c_int32), ("fused_residual", C.c_int32),
-                ("fused_decode", C.c_int32), ("flops_per_frame", C.c_int64),
+                ("fused_decode", C.c_int32), ("fused_pointwise", C.c_int32), ("flops_per_frame", C.c_int64),
                 ("bytes_per_frame", C.c_int64), ("weight_bytes", C.c_int64)]
 
 

@@ -12,7 +12,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int HBK = 32;                  // K elements per LDS stage (64 bytes per panel row)
 constexpr unsigned OOB = 0x80000000u;    // voffset beyond any buffer (< 2 GiB enforced on the host)
 
-enum { EPI_SPLIT = 0, EPI_SPLIT_RES = 1, EPI_DECODE = 2 };
+enum { EPI_SPLIT = 0, EPI_SPLIT_RES = 1, EPI_DECODE = 2, EPI_SPLIT_PW = 3, EPI_SPLIT_RES_PW = 4 };
+constexpr int PW_MAX_COUT = 64, PW_MAX_K = 64;    // measured: hosts with 128 output channels gain nothing over the stand-alone 1x1 kernel
 
 __device__ __forceinline__ float h_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -65,16 +66,42 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                                                     int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M) {
     constexpr int TM = WM / MT, TN = WN / MT, NE = MT * MT / 64;
     static_assert(sizeof(AccT) == NE * 4, "accumulator type / MFMA tile");
+    constexpr bool PW = EPI == EPI_SPLIT_PW || EPI == EPI_SPLIT_RES_PW;
+    constexpr bool RES = EPI == EPI_SPLIT_RES || EPI == EPI_SPLIT_RES_PW;
+    // fused pointwise conv: the transpose tile doubles as the A operand of the second GEMM (row stride + 4 floats: the
+    // 16 rows x 16 bytes of a fragment read then cover all 64 banks), and a second tile T2 takes its result
+    constexpr int TS = PW ? BN + 4 : BN;
+    constexpr int T2S = PW_MAX_COUT + 4;
     // ---- epilogue.  The accumulators (MFMA layout: channel on the lane, 16 pixel rows per register set)
     // are scaled / biased / activated and transposed through LDS (the stage buffers are dead: the main
     // loop ended on a barrier) as an fp32 [rows][BN] tile, so that the residual loads and the output
     // stores are row-contiguous 16-byte accesses (split format) or 256-byte row segments (decode).
-    constexpr int RG_MAX = SMEM_BYTES / (BN * 4);
+    constexpr int RG_MAX = SMEM_BYTES / ((TS + (PW ? T2S : 0)) * 4);
     constexpr int RG = epi_row_group(BM, WM, RG_MAX);                     // rows per pass: multiple of WM dividing BM
     static_assert(RG >= WM && BM % RG == 0, "epilogue row group");
     float* T = reinterpret_cast<float*>(smem);
     const int hw = a.Ho * a.Wo;
     const bool st_plain = (a.dbg & 8) != 0;
+    // fused pointwise conv: a wave owns one 16-column group of the second GEMM; its B fragments (the whole K of the
+    // 1x1 conv, <= 4 k32 steps) are fetched once here, their latency hidden behind the transpose and the first store pass
+    constexpr int PWK = PW_MAX_K / 32;
+    f16x8 b2h[PW ? PWK : 1], b2l[PW ? PWK : 1];
+    float bias2 = 0.f, inv2 = 0.f;
+    int pw_n2t = 1, pw_j = 0;
+    if constexpr (PW) {
+        pw_n2t = a.pw_cout / 16;                                  // 1, 2 or 4: divides the wave count
+        pw_j = (tid >> 6) % pw_n2t;
+        const int n2 = pw_j * 16 + (tid & 15);
+        const _Float16* w2h = a.pw_wh + (int64_t)n2 * a.pw_k + ((tid & 63) >> 4) * 8;
+        const _Float16* w2l = a.pw_wl + (int64_t)n2 * a.pw_k + ((tid & 63) >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < PWK; ++ks) {
+            const bool ok = ks * 32 < a.pw_k;
+            b2h[ks] = ok ? *reinterpret_cast<const f16x8*>(w2h + ks * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            b2l[ks] = ok ? *reinterpret_cast<const f16x8*>(w2l + ks * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        bias2 = a.pw_bias[n2] * SPLIT_SCALE; inv2 = a.pw_inv_scale[n2] * SPLIT_SCALE;
+    }
     const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
 #pragma unroll 1
     for (int rg = 0; rg < BM; rg += RG) {
@@ -92,7 +119,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                         const int rl = wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh;
                         float v = acc[i][j][e] * inv + bias;
                         if (a.leaky) v = v > 0.f ? v : v * 0.1f;
-                        T[rl * BN + nl] = v;
+                        T[rl * TS + nl] = v;
                     }
             }
         }
@@ -113,7 +140,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 int b = m / hw, cell = m - b * hw;
                 int gy = cell / a.dec.G, gx = cell - gy * a.dec.G;
                 for (int r = r0; r < RG && m < M; r += RSTEP, m += RSTEP) {
-                    const float v = T[r * BN + nl];
+                    const float v = T[r * TS + nl];
                     float o;
                     if (is_raw) o = v;
                     else {
@@ -137,15 +164,19 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 const int r = g / GPR, c8 = (g - r * GPR) * 8;
                 const int m = bm * BM + rg + r;
                 if (m >= M || bn * BN + c8 >= a.Cout) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + c8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + c8 + 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * TS + c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if constexpr (EPI == EPI_SPLIT_RES) {
+                if constexpr (RES) {
                     const _Float16* q = rh + (int64_t)m * 2 * a.res_ldc + c8;
                     const f16x8 qh = *reinterpret_cast<const f16x8*>(q);
                     const f16x8 ql = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
+                    if constexpr (PW) {                                   // the second GEMM reads the sum
+                        *reinterpret_cast<f32x4*>(T + r * TS + c8) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(T + r * TS + c8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
                 }
                 f16x8 ph, pl;
 #pragma unroll
@@ -157,6 +188,65 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
                 store_act16(q, ph, st_plain);
                 store_act16(q + a.out_ldc, pl, st_plain);
+            }
+            if constexpr (PW) {
+                // ---- fused 1x1 conv: out2[RG x pw_cout] = act[RG x pw_k] * W2^T, same three-product split arithmetic.
+                // T holds this conv's activations x SPLIT_SCALE (the stored format), so hi / lo come from it directly.
+                // Work item = one 16x16 output tile; A from T (ds_read_b128 pairs), B straight from the 1x1 conv's packed
+                // planes (a few KiB, L1/L2 resident).
+                __syncthreads();
+                float* T2 = T + RG * TS;
+                const int lane = tid & 63, wave = tid >> 6;
+                const int lr16 = lane & 15, lh16 = lane >> 4;
+                const int k2s = a.pw_k / 32;
+                const int n2 = pw_j * 16 + lr16;
+                for (int sl = wave / pw_n2t; sl < RG / 16; sl += (NT / 64) / pw_n2t) {
+                    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                    const float* trow = T + (sl * 16 + lr16) * TS + lh16 * 8;
+#pragma unroll
+                    for (int ks = 0; ks < PWK; ++ks) {
+                        if (ks < k2s) {                                   // uniform
+                            const f32x4 x0 = *reinterpret_cast<const f32x4*>(trow + ks * 32);
+                            const f32x4 x1 = *reinterpret_cast<const f32x4*>(trow + ks * 32 + 4);
+                            f16x8 ah, al;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float x = e < 4 ? x0[e] : x1[e - 4];
+                                const _Float16 h = (_Float16)x;
+                                ah[e] = h; al[e] = (_Float16)(x - (float)h);
+                            }
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b2h[ks], acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b2l[ks], acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b2h[ks], acc2, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[e] * inv2 + bias2;
+                        if (a.pw_leaky) v = v > 0.f ? v : v * 0.1f;
+                        T2[(sl * 16 + 4 * lh16 + e) * T2S + n2] = v;
+                    }
+                }
+                __syncthreads();
+                const int gpr2 = a.pw_cout / 8;
+                _Float16* oh2 = reinterpret_cast<_Float16*>(a.pw_out) + a.pw_out_coff;
+                for (int g = tid; g < RG * gpr2; g += NT) {
+                    const int r = g / gpr2, c8 = (g - r * gpr2) * 8;
+                    const int m = bm * BM + rg + r;
+                    if (m >= M) continue;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(T2 + r * T2S + c8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(T2 + r * T2S + c8 + 4);
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = e < 4 ? v0[e] : v1[e - 4];
+                        const _Float16 h = (_Float16)v;
+                        ph[e] = h; pl[e] = (_Float16)(v - (float)h);
+                    }
+                    _Float16* q = oh2 + (int64_t)m * 2 * a.pw_out_ldc + c8;
+                    store_act16(q, ph, st_plain);
+                    store_act16(q + a.pw_out_ldc, pl, st_plain);
+                }
             }
         }
         if (rg + RG < BM) __syncthreads();

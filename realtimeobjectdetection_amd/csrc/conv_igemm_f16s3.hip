@@ -270,7 +270,14 @@ static int launch_h(const ConvArgs& a, hipStream_t s) {
     auto k_dec = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_DECODE>;
     auto k_res = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES>;
     auto k_plain = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT>;
-    if (a.dec.enabled) hipLaunchKernelGGL(k_dec, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
+    auto k_res_pw = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES_PW>;
+    auto k_pw = conv_igemm_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_PW>;
+    if (a.pw_wh) {
+        if (gn != 1 || a.dec.enabled) { set_error("conv_igemm_f16s3: fused pointwise conv needs Cout <= BN (%d > %d) and no decode", a.Cout, BN); return RTOD_E_ARG; }
+        if (a.res) hipLaunchKernelGGL(k_res_pw, dim3(gm), dim3(NT), 0, s, a, gm, gn);
+        else hipLaunchKernelGGL(k_pw, dim3(gm), dim3(NT), 0, s, a, gm, gn);
+    }
+    else if (a.dec.enabled) hipLaunchKernelGGL(k_dec, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     else if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_igemm_f16s3 launch");
@@ -285,6 +292,10 @@ int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
     }
     if (!a.dec.enabled && (a.out_ldc % 1 || a.out_ldc <= 0)) { set_error("launch_conv_f16s3: bad output view"); return RTOD_E_ARG; }
     if (a.B <= 0 || a.Ho <= 0 || a.Wo <= 0 || a.Cout <= 0) { set_error("launch_conv_f16s3: empty shape"); return RTOD_E_ARG; }
+    if (a.pw_wh && (!a.pw_wl || !a.pw_inv_scale || !a.pw_bias || !a.pw_out || a.pw_k != a.Cout || a.pw_k % 32 || a.pw_k > PW_MAX_K ||
+                    (a.pw_cout != 16 && a.pw_cout != 32 && a.pw_cout != 64) || a.pw_out_ldc % 8 || a.pw_out_coff % 8)) {
+        set_error("launch_conv_f16s3: bad fused pointwise conv (k=%d cout=%d, conv Cout=%d)", a.pw_k, a.pw_cout, a.Cout); return RTOD_E_ARG;
+    }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) {
         set_error("launch_conv_f16s3: buffer of %u / %u bytes outside (0, 2 GiB)", a.in_bytes, a.w_bytes); return RTOD_E_ARG;
     }

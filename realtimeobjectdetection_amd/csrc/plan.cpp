@@ -402,6 +402,17 @@ int Plan::plan_buffers() {
                 break;
         }
     }
+    // fused-pointwise candidates: conv launch i immediately followed by a 1x1 / stride 1 conv launch that reads exactly
+    // i's output, with Cout_i <= 64 (one N tile; wider hosts measured no gain), Cout_j in {16, 32, 64}, no residual / decode on j (conv_f16s3_common.h)
+    for (size_t i = 0; i + 1 < launches.size(); ++i) {
+        Launch& h = launches[i]; Launch& g = launches[i + 1];
+        if (h.kind != LK_CONV || g.kind != LK_CONV || h.out_layer < 0 || g.out_layer < 0 || g.in2_layer >= 0 || h.pw_host >= 0) continue;
+        const Layer& H = layers[h.layer]; const Layer& G = layers[g.layer];
+        if (g.in_layer != h.out_layer || G.size != 1 || G.stride != 1 || G.pad != 0 || G.cin != H.cout) continue;
+        if (H.cout % 32 || H.cout > 64 || (G.cout != 16 && G.cout != 32 && G.cout != 64) || G.fused_into >= 0) continue;   // PW_MAX_K
+        if (conv_band_supported(H.size, H.stride, H.pad, H.cin, H.win) && H.hout == H.hin) continue;   // band kernel: no pointwise epilogue
+        h.pw_guest = (int)i + 1; g.pw_host = (int)i;
+    }
     // liveness per buffer over launch time (= layer index of the launch)
     const int NB = (int)bufs.size();
     for (auto& b : bufs) { b.first = 1 << 30; b.last = -1; }
@@ -415,6 +426,7 @@ int Plan::plan_buffers() {
         if (l.in2_layer >= 0) touch(buf_of_layer(l.in2_layer), t);
         if (l.kind == LK_COPY) touch(l.out_buf, t);
         else if (l.out_layer >= 0) touch(buf_of_layer(l.out_layer), t);
+        if (l.pw_guest >= 0) touch(buf_of_layer(launches[l.pw_guest].out_layer), t);     // written by the host's epilogue when fused
     }
     // a concat buffer is live from its first producer to its last consumer: touches above cover both
     for (int b = 0; b < NB; ++b) {
@@ -708,6 +720,18 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
         if (!r.base || r.C != L.cout || r.H != L.hout || r.W != L.wout) { set_error("forward: layer %d residual view mismatch", l.layer); return RTOD_E_STATE; }
         a.res = r.base; a.res_ldc = r.ldc; a.res_coff = r.coff;
     }
+    if (l.pw_guest >= 0 && pw_active()) {
+        const Launch& g = launches[l.pw_guest];
+        const Layer& G = layers[g.layer];
+        const PackedConv& gc = convs[g.conv_slot];
+        const View o = view_of(g.out_layer);
+        if (!gc.split || gc.Kpad != L.cout || !o.base || !o.split || o.C != G.cout || o.H != L.hout || o.W != L.wout) { set_error("forward: layer %d fused pointwise mismatch", g.layer); return RTOD_E_STATE; }
+        a.pw_wh = reinterpret_cast<const _Float16*>(d_weights + gc.w_off);
+        a.pw_wl = reinterpret_cast<const _Float16*>(d_weights + gc.wl_off);
+        a.pw_inv_scale = d_weights + gc.s_off; a.pw_bias = d_weights + gc.b_off;
+        a.pw_out = o.base; a.pw_out_ldc = o.ldc; a.pw_out_coff = o.coff;
+        a.pw_cout = G.cout; a.pw_k = L.cout; a.pw_leaky = G.leaky ? 1 : 0;
+    }
     return RTOD_OK;
 }
 
@@ -721,7 +745,8 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
 int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     const Launch& l = launches[li];
     const Layer& L = layers[l.layer];
-    const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2};
+    const bool pw = a.pw_wh != nullptr;
+    const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2, pw ? a.pw_cout : 0};
     auto it = tune_cache.find(key);
     if (it != tune_cache.end()) { tuning[li] = it->second; return RTOD_OK; }
     hipEvent_t e0, e1;
@@ -733,6 +758,7 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
         for (int v = 0; v < HV_COUNT; ++v) {
             const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
             if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;       // tile far wider than the layer
+            if (pw && vi.bn < L.cout) continue;                                       // fused pointwise: one N tile
             cand.push_back(v);
         }
     }
@@ -784,13 +810,21 @@ int Plan::variant_for(const Launch& l, int batch) const {
     if (force && *force) {                                   // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
         const int v = atoi(force);
         if (band) return v >= BAND_VARIANT_BASE && v < BAND_VARIANT_BASE + BAND_MODES ? v : BAND_VARIANT_BASE;
-        return choose_variant_f16s3(layers[l.layer], batch);
+        const int g = choose_variant_f16s3(layers[l.layer], batch);
+        if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;
+        return g;
     }
     auto it = tuned.find(batch);
     const size_t idx = &l - &launches[0];
     if (it != tuned.end() && idx < it->second.size() && it->second[idx] >= 0) return it->second[idx];
-    return band ? BAND_VARIANT_BASE : choose_variant_f16s3(layers[l.layer], batch);
+    if (band) return BAND_VARIANT_BASE;
+    const int v = choose_variant_f16s3(layers[l.layer], batch);
+    // host of a fused pointwise conv: one N tile must cover every output channel
+    if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(v).bn < layers[l.layer].cout) return HV_128x128_8W;
+    return v;
 }
+
+bool Plan::pw_active() const { return precision == 1 && !getenv("RTOD_NO_PW"); }
 
 int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
     const char* force = getenv("RTOD_F16S3_VARIANT");
@@ -828,6 +862,7 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
             case LK_CONV: {
                 const Layer& L = layers[l.layer];
                 const PackedConv& pc = convs[l.conv_slot];
+                if (l.pw_host >= 0 && pw_active()) break;           // runs in the host conv's epilogue
                 ConvArgs a;
                 rc = build_conv_args(l, batch, out, a);
                 if (rc) return rc;
@@ -896,11 +931,19 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
             o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
             break;
         case LK_CONV:
+            if (l.pw_host >= 0 && pw_active()) { o->bytes_per_frame = 0; break; }    // accounted on the host conv's launch
             o->variant = convs[l.conv_slot].split ? 100 + variant_for(l, batch) : choose_variant(L, batch);
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
             o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
             o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);
             o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
+            if (l.pw_guest >= 0 && pw_active()) {
+                const Layer& G = layers[launches[l.pw_guest].layer];
+                o->fused_pointwise = 1;
+                o->flops_per_frame += 2ll * G.hout * G.wout * G.cout * G.cin;
+                o->bytes_per_frame += (int64_t)G.hout * G.wout * G.cout * 4;
+                o->weight_bytes += ((int64_t)G.cout * G.cin + G.cout) * 4;
+            }
             break;
         case LK_ADD: o->bytes_per_frame = 3 * out_b; break;
         default: o->bytes_per_frame = in_b + out_b; break;

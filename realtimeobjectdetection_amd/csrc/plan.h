@@ -47,6 +47,11 @@ struct Launch {
     int out_buf = -1, out_coff = 0;   // for LK_COPY into a concat slice
     int conv_slot = -1;       // index into Plan::convs
     DecodeArgs dec;
+    // split-f16 plans: a 1x1 conv that directly follows a conv whose workgroups hold all output channels runs in that
+    // conv's epilogue (conv_f16s3_common.h).  pw_guest: launch index of the 1x1 conv hosted by this launch; pw_host:
+    // launch index of the host (this launch is then skipped).  Candidates are found at plan build (liveness covers
+    // both schedules); Plan::pw_active() decides at run time.
+    int pw_guest = -1, pw_host = -1;
 };
 
 struct PackedConv {
@@ -97,6 +102,7 @@ struct Plan {
     std::map<std::vector<int>, int> tune_cache;
     int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
+    bool pw_active() const;                     // fused pointwise convs in use (precision 1, RTOD_NO_PW unset)
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)
     std::string describe() const;
     void fill_launch_info(int idx, rtod_launch_info* o, int batch) const;

@@ -63,6 +63,14 @@ struct ConvArgs {
     unsigned in_bytes = 0, w_bytes = 0;         // extents of the input buffer / one weight plane (buffer-load range check)
     int dbg = 0;                                // timing experiments only (RTOD_DBG_ZERO)
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
+    // split path, fused trailing 1x1 conv ("pointwise", conv_f16s3_common.h): the workgroup holds every channel of its
+    // output pixels (Cout <= BN), so the next layer's 1x1 convolution runs as a second small GEMM in the epilogue
+    const _Float16* pw_wh = nullptr;            // [pw_cout..][pw_k] hi / lo planes of the 1x1 conv (its own packed weights)
+    const _Float16* pw_wl = nullptr;
+    const float* pw_inv_scale = nullptr;
+    const float* pw_bias = nullptr;
+    float* pw_out = nullptr;    int64_t pw_out_ldc = 0; int pw_out_coff = 0;
+    int pw_cout = 0, pw_k = 0, pw_leaky = 0;    // pw_k = Cout of this conv = Kpad of the 1x1 (32 or 64); pw_cout 16, 32 or 64
 };
 
 // Split activation format: value * SPLIT_SCALE stored as f16 hi + f16 lo planes per pixel.
