@@ -66,10 +66,13 @@ __host__ __device__ constexpr int band_rows(int bm, int w) { return (bm + 2 * w 
 //                 MFMA utilisation than a larger wave tile
 //   192x128, 4x2 / 6x2: 8 waves of 48x64 or 12 of 32x64 — 76x76x8 pixels are 482 tiles instead of 722, 38x38x8 244
 //   96x128, 2x4: 8 waves of 48x32 — 19x19x8 pixels x 1024 channels are 248 tiles instead of 184
-template <int BM, int BN, int NWM, int NWN, int MINW, int EPI>
-__global__ __launch_bounds__(NWM * NWN * 64, MINW)
+// KG = 2: in-workgroup split-K.  Two groups of NWM x NWN waves each run the whole pipeline (own band, own weight
+// stages) on the even / odd 32-channel chunks and the epilogue sums the two accumulator sets through LDS.  For layers
+// whose grid cannot give a CU two workgroups (19x19: 248 tiles) this is what puts 16 waves on the CU.
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, int KG>
+__global__ __launch_bounds__(NWM * NWN * 64 * KG, MINW)
 void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
-    constexpr int WM = BM / NWM, WN = BN / NWN, NT = NWM * NWN * 64;
+    constexpr int WM = BM / NWM, WN = BN / NWN, NT = NWM * NWN * 64;   // NT = threads of one K group
     static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int RPP = NT / 4;                               // rows per staging pass (4 x 16-B chunks per row)
@@ -86,8 +89,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int W = a.Wi, H = a.Hi;
     const int NBR = band_rows(BM, W);                          // band rows incl. padding; the zero row is row NBR
     const int plane = (NBR + 1) * 64;
-    unsigned char* bst = smem;                                 // [2 stages][hi, lo][BN][64]
-    unsigned char* bandh = smem + 2 * BSTAGE;
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);   // K group of this wave (uniform -> SGPR)
+    unsigned char* bst = smem + kg * (2 * BSTAGE + 2 * plane); // per group: [2 stages][hi, lo][BN][64], then the band
+    unsigned char* bandh = bst + 2 * BSTAGE;
     unsigned char* bandl = bandh + plane;
     const int zero_off = NBR * 64;
 
@@ -99,7 +103,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     }
     const int bm = bid / grid_n, bn = bid - bm * grid_n;
 
-    const int tid = threadIdx.x;
+    const int tid = KG == 1 ? (int)threadIdx.x : (int)threadIdx.x - kg * NT;   // thread index within the K group
     const int M = a.B * H * W;                                 // Ho == Hi, Wo == Wi
     const int m0 = bm * BM;
     const int NB = BM + 2 * W + 2;
@@ -127,7 +131,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
 
-    const int n_cc = a.Cin / 32;
+    const int n_cc = a.Cin / 32 / KG;                          // channel chunks of this group: kg, kg + KG, ...
     const int nsteps = 9 * n_cc;
 
     // ---- per-lane validity of the 9 taps for the TM 16-row tiles this wave reads
@@ -159,10 +163,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     BStage S0, S1;
     u32x4 BRh[BAND_SLOTS], BRl[BAND_SLOTS];
 
-    int ld_step = 0;                                           // B chunk to be loaded next (== (cc*9 + tap))
+    int ld_step = 0, ld_cc = 0, ld_tap = 0;                    // B chunk to be loaded next: local step, its chunk and tap
     auto gload_b = [&](BStage& S) {
         const bool live = ld_step < nsteps;
-        const unsigned koff = (unsigned)ld_step * (HBK * 2);
+        const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * (HBK * 2);
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const unsigned wo = live ? wbase[i] : OOB;
@@ -170,10 +174,11 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             S.bl[i] = asm_buffer_load_b128(rs_wl, wo, koff);
         }
         ++ld_step;
+        if (++ld_tap == 9) { ld_tap = 0; ++ld_cc; }
     };
     auto gload_band = [&](int cc) {
         const bool live = cc < n_cc;
-        const unsigned soff = (unsigned)cc * 64u;
+        const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
 #pragma unroll
         for (int j = 0; j < BAND_SLOTS; ++j) {
             const unsigned vo = live ? bvo[j] : OOB;
@@ -305,32 +310,43 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __syncthreads();
 
     if (a.dbg & 4) return;
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, BAND_EPI_BYTES, 16, f32x4>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, 16, f32x4, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 }
 
-template <int BM, int BN, int NWM, int NWN, int MINW>
+template <int BM, int BN, int NWM, int NWN, int MINW, int KG = 1>
 static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
-    const int main_bytes = 4 * BN * 64 + 2 * (band_rows(BM, a.Wi) + 1) * 64;
+    if (a.Cin % (32 * KG)) { set_error("launch_conv_band: Cin=%d not a multiple of %d", a.Cin, 32 * KG); return RTOD_E_ARG; }
+    const int main_bytes = KG * (4 * BN * 64 + 2 * (band_rows(BM, a.Wi) + 1) * 64);
     const int lds = main_bytes > BAND_EPI_BYTES ? main_bytes : BAND_EPI_BYTES;
-    auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES>;
-    auto k_plain = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT>;
+    auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, KG>;
+    auto k_plain = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, KG>;
     static unsigned long long attr_done = 0;                   // per instantiation and device; > 64 KiB of dynamic LDS needs the opt-in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_band_f16s3 hipGetDevice");
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        const int cap = 4 * BN * 64 + 2 * (band_rows(BM, BAND_MAX_W) + 1) * 64;
+        const int cap = KG * (4 * BN * 64 + 2 * (band_rows(BM, BAND_MAX_W) + 1) * 64);
         const int mx = cap > BAND_EPI_BYTES ? cap : BAND_EPI_BYTES;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return hip_fail(hipGetLastError(), "conv_band_f16s3 LDS attribute");
         attr_done |= 1ull << (dev & 63);
     }
-    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64), lds, s, a, gm, gn);
-    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64), lds, s, a, gm, gn);
+    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, a, gm, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, a, gm, gn);
     return hip_fail(hipGetLastError(), "conv_band_f16s3 launch");
 }
+
+// Split-K changes the summation order, and a layer's result must not depend on the batch it runs in (tile choice does):
+// whether a layer runs split-K is therefore a property of the layer alone — deep (Cin >= 512) and small (<= 400 pixels:
+// the 19x19 / 13x13 stages, whose grid cannot give a CU two workgroups at any realistic batch).
+int conv_band_layer_kg(int cin, int h, int w) { return (cin % 64 == 0 && cin >= 512 && h * w <= 400) ? 2 : 1; }
+bool conv_band_mode_valid(int mode, int cin, int h, int w) {
+    if (mode < 0 || mode >= BAND_MODES) return false;
+    return (mode >= BAND_K2_MODE0 ? 2 : 1) == conv_band_layer_kg(cin, h, w);
+}
+int conv_band_default_mode(int cin, int h, int w) { return conv_band_layer_kg(cin, h, w) == 2 ? BAND_K2_MODE0 : 0; }
 
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && w_in <= BAND_MAX_W;
@@ -344,6 +360,8 @@ static const ConvVariantInfo kBandModes[BAND_MODES] = {
     {96, 128, "conv_band_f16s3<96x128,2x4>"},
     {128, 128, "conv_band_f16s3<128x128,2x2>"},
     {64, 128, "conv_band_f16s3<64x128,2x4>"},
+    {96, 128, "conv_band_f16s3<96x128,2x4,k2>"},
+    {128, 128, "conv_band_f16s3<128x128,4x2,k2>"},
 };
 const ConvVariantInfo& conv_band_mode_info(int mode) { return kBandModes[mode < 0 || mode >= BAND_MODES ? 0 : mode]; }
 
@@ -368,6 +386,8 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
         case 4: return launch_band<96, 128, 2, 4, 4>(a, s);
         case 5: return launch_band<128, 128, 2, 2, 2>(a, s);
         case 6: return launch_band<64, 128, 2, 4, 4>(a, s);
+        case 7: return launch_band<96, 128, 2, 4, 4, 2>(a, s);
+        case 8: return launch_band<128, 128, 4, 2, 4, 2>(a, s);
     }
     set_error("launch_conv_band: mode %d unsupported", mode);
     return RTOD_E_ARG;

@@ -61,9 +61,12 @@ constexpr int epi_row_group(int bm, int wm, int rg_max) {
 // `smem` is the kernel's whole LDS allocation (dead after the main loop, which must end on a barrier).
 // MT = MFMA tile edge: 32 (v_mfma_f32_32x32x16_f16: lane holds column lane%32, rows (e&3) + 8(e>>2) + 4(lane/32)) or
 // 16 (v_mfma_f32_16x16x32_f16: column lane%16, rows e + 4(lane/16)).
-template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int MT = 32, typename AccT = f32x16>
+// KG = 2 (in-workgroup split-K, conv_band_f16s3.hip): NT counts both wave groups, `tid` is the workgroup-wide thread
+// index, wm / wn are positions inside the group `kg`; group 1 deposits its raw accumulators in the tile first and
+// group 0 adds its own before scale / bias / activation.
+template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int MT = 32, typename AccT = f32x16, int KG = 1>
 __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&acc)[WM / MT][WN / MT], unsigned char* smem,
-                                                    int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M) {
+                                                    int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M, int kg = 0) {
     constexpr int TM = WM / MT, TN = WN / MT, NE = MT * MT / 64;
     static_assert(sizeof(AccT) == NE * 4, "accumulator type / MFMA tile");
     constexpr bool PW = EPI == EPI_SPLIT_PW || EPI == EPI_SPLIT_RES_PW;
@@ -105,7 +108,19 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
     const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
 #pragma unroll 1
     for (int rg = 0; rg < BM; rg += RG) {
-        if (wm * WM >= rg && wm * WM < rg + RG) {
+        if constexpr (KG == 2) {
+            if (kg == 1 && wm * WM >= rg && wm * WM < rg + RG) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < NE; ++e)
+                            T[(wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh) * TS + wn * WN + j * MT + lr] = acc[i][j][e];
+            }
+            __syncthreads();
+        }
+        if (kg == 0 && wm * WM >= rg && wm * WM < rg + RG) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nl = wn * WN + j * MT + lr;
@@ -117,7 +132,9 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
                         const int rl = wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh;
-                        float v = acc[i][j][e] * inv + bias;
+                        float s = acc[i][j][e];
+                        if constexpr (KG == 2) s += T[rl * TS + nl];
+                        float v = s * inv + bias;
                         if (a.leaky) v = v > 0.f ? v : v * 0.1f;
                         T[rl * TS + nl] = v;
                     }

@@ -753,7 +753,7 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     RTOD_HIP(hipEventCreate(&e0)); RTOD_HIP(hipEventCreate(&e1));
     std::vector<int> cand;
     if (convs[l.conv_slot].band) {                                                    // band layers: band tiles only (see rtod_internal.h)
-        for (int m = 0; m < BAND_MODES; ++m) cand.push_back(BAND_VARIANT_BASE + m);
+        for (int m = 0; m < BAND_MODES; ++m) if (conv_band_mode_valid(m, L.cin, L.hin, L.win)) cand.push_back(BAND_VARIANT_BASE + m);
     } else {
         for (int v = 0; v < HV_COUNT; ++v) {
             const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
@@ -809,7 +809,8 @@ int Plan::variant_for(const Launch& l, int batch) const {
     const bool band = convs[l.conv_slot].band;
     if (force && *force) {                                   // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
         const int v = atoi(force);
-        if (band) return v >= BAND_VARIANT_BASE && v < BAND_VARIANT_BASE + BAND_MODES ? v : BAND_VARIANT_BASE;
+        const Layer& FL = layers[l.layer];
+        if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
         const int g = choose_variant_f16s3(layers[l.layer], batch);
         if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;
         return g;
@@ -817,7 +818,7 @@ int Plan::variant_for(const Launch& l, int batch) const {
     auto it = tuned.find(batch);
     const size_t idx = &l - &launches[0];
     if (it != tuned.end() && idx < it->second.size() && it->second[idx] >= 0) return it->second[idx];
-    if (band) return BAND_VARIANT_BASE;
+    if (band) return BAND_VARIANT_BASE + conv_band_default_mode(layers[l.layer].cin, layers[l.layer].hin, layers[l.layer].win);
     const int v = choose_variant_f16s3(layers[l.layer], batch);
     // host of a fused pointwise conv: one N tile must cover every output channel
     if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(v).bn < layers[l.layer].cout) return HV_128x128_8W;

@@ -89,7 +89,12 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 // A layer the band kernel supports ALWAYS runs on it (16x16x32 MFMA; the generic kernel's 32x32x16 rounds differently, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
-constexpr int BAND_MODES = 7;              // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4
+constexpr int BAND_MODES = 9;              // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
+                                           // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2
+constexpr int BAND_K2_MODE0 = 7;
+int conv_band_layer_kg(int cin, int h, int w);
+bool conv_band_mode_valid(int mode, int cin, int h, int w);
+int conv_band_default_mode(int cin, int h, int w);
 const ConvVariantInfo& conv_band_mode_info(int mode);
 int launch_conv_band_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the band kernel: BAND_VARIANT_BASE + mode
