@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("RTOD_PRECISION", "f16s3"), choices=["fp32", "f16s3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-nms", action="store_true", help="run write_results on the forward's stream (no overlap with the next batch)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight: steps alternate over N plans (own activation arena) on N HIP streams, so one batch's "
+                         "partial rounds, prologues and epilogues overlap the other's kernels; 1 = strictly sequential forwards")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
     args = ap.parse_args()
@@ -205,6 +208,10 @@ def main():
     from realtimeobjectdetection_amd.util import write_results_async
     B, R = args.batch, args.res
     model, ir, w, cfg_text = build_model(R, dev, B, args.precision)
+    extra = [build_model(R, dev, B, args.precision)[0] for _ in range(max(0, args.inflight - 1))]
+    models = [model] + extra
+    fstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in extra]
+    step_no = [0]
     # this rank's frame shard: frames [rank*B, (rank+1)*B) of the global synthetic stream
     x = torch.from_numpy(synth.synth_frames(B, R, seed=synth.FRAME_SEED + rank)).to(dev)
     CAP = 4096                                          # rows gathered per rank (fixed-capacity, no host sync)
@@ -225,34 +232,50 @@ def main():
             dist.all_gather_into_tensor(g_counts, counts[:2].contiguous())
         return rows, counts
 
-    def step():
-        with torch.no_grad():
-            y = model(x)
+    def step(nm):
+        i = step_no[0] % nm; step_no[0] += 1
+        with torch.no_grad(), torch.cuda.stream(fstreams[i]):
+            y = models[i](x)
             if side is None:
                 rows, counts = post(y)
             else:
-                side.wait_stream(torch.cuda.current_stream(dev))
+                side.wait_stream(fstreams[i])
                 with torch.cuda.stream(side):
                     rows, counts = post(y)
                 y.record_stream(side)
         return y, rows, counts
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
+    def timed_run(nm):
+        """W untimed + K timed steps with `nm` batches in flight; returns (seconds, last step's tensors)."""
+        step_no[0] = 0
+        for _ in range(args.warmup):
+            step(nm)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(nm)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    with torch.no_grad():                               # set-up, not a step: every plan's first forward autotunes its tiles
+        for m_ in models:
+            m_(x)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y, rows, counts = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, (y, rows, counts) = timed_run(len(models))
+    single = None
+    if len(models) > 1:                                 # the strictly sequential figure beside the pipelined one
+        dt1, _ = timed_run(1)
+        single = {"value": round(world * B * args.steps / dt1, 2), "unit": "frames/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                  "note": "one batch in flight (forward i+1 starts after forward i; write_results still overlapped)"}
     fps = world * B * args.steps / dt
     n_det, n_cand = [int(v) for v in counts[:2].tolist()]
 
@@ -284,11 +307,14 @@ def main():
                                    % (R, R, B, "exact-fp32" if args.precision == "fp32" else "split-f16", 2 if R == 608 else 1),
                        "precision": args.precision,
                        "frames_per_step": world * B, "parallelism": "frame-shard x%d" % world,
+                       "in_flight_batches": len(models), "write_results_stream": "same" if args.serial_nms else "second stream",
                        "conf": args.conf, "nms": args.nms, "detections_last_step": n_det, "candidates_last_step": n_cand,
                        "conv_gflop_per_frame": round(ir.conv_flops / 1e9, 3),
                        "whole_path_tflops": round(fps * ir.conv_flops / 1e12, 2),
                        "whole_path_frac_fp32_mfma_peak": round(fps * ir.conv_flops / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)},
         }
+        if single is not None:
+            line["single_stream"] = single
         if roof is not None:
             line["roofline"] = roof
         if cpu is not None:
