@@ -337,3 +337,74 @@ def test_heuristic_variants_without_autotune_and_batch_growth(tmp_path_factory, 
     rows = y2[:, ::int(g["row_stride"]), :].cpu().numpy()
     assert rel_err(rows, g["rows"]).max() <= TOL
     assert rel_err(y1.cpu().numpy(), y2[:1].cpu().numpy()).max() <= 5e-5
+
+
+# ------------------------------------------------------------------------------- scheduling variants keep the bits
+def _fresh_f16s3(tmp_path_factory, tag, res=416):
+    from realtimeobjectdetection_amd.darknet import Darknet
+    d = tmp_path_factory.mktemp(tag)
+    cfg_text = NETS["yolov3"]()
+    m = Darknet(cfgs.write_cfg(str(d / "yolov3.cfg"), cfg_text), True).eval()
+    m.net_info["height"] = res
+    m.precision = "f16s3"
+    m.load_weight_stream(synth.synth_weights(O.RefDarknet(cfg_text, res).ir))
+    return m
+
+
+def test_fused_pointwise_epilogue_is_bit_identical(tmp_path_factory, monkeypatch):
+    """The 1x1 conv that runs in the previous conv's epilogue (layer 1 -> 2) sums its K products in the stand-alone
+    kernel's order: switching the fusion off (RTOD_NO_PW) must not change a single bit of any layer."""
+    x = torch.from_numpy(synth.synth_frames(2, 416)).cuda()
+    ma = _fresh_f16s3(tmp_path_factory, "pw_on")
+    ma.keep_all_layers = True
+    with torch.no_grad():
+        ya = ma(x).clone()
+    infos = ma.launch_infos()
+    assert any(li.fused_pointwise for li in infos), "yolov3 layer 1 should host layer 2's 1x1 conv"
+    l2a = ma.read_layer(2, 2).clone()
+    monkeypatch.setenv("RTOD_NO_PW", "1")
+    mb = _fresh_f16s3(tmp_path_factory, "pw_off")
+    mb.keep_all_layers = True
+    with torch.no_grad():
+        yb = mb(x).clone()
+    assert not any(li.fused_pointwise for li in mb.launch_infos())
+    assert torch.equal(l2a, mb.read_layer(2, 2))
+    assert torch.equal(ya, yb)
+
+
+def test_two_plans_on_two_streams_match_single_stream(tmp_path_factory):
+    """bench.py keeps two batches in flight: two plans (own arenas) on two HIP streams, write_results on a third.
+    Interleaved execution must give exactly the single-stream results."""
+    from realtimeobjectdetection_amd.util import write_results_async
+    xs = [torch.from_numpy(synth.synth_frames(2, 416, seed=synth.FRAME_SEED + i)).cuda() for i in range(4)]
+    m0 = _fresh_f16s3(tmp_path_factory, "if0")
+    m1 = _fresh_f16s3(tmp_path_factory, "if1")
+    with torch.no_grad():
+        want = [m0(x).clone() for x in xs]
+        want_rows = []
+        for y in want:
+            r, c = write_results_async(y, 80, 0.6, 0.5, cap=4096)
+            want_rows.append((r.clone(), c.clone()))
+        m1(xs[0])                                                  # set-up forward (autotune) outside the pipelined part
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    side = torch.cuda.Stream()
+    got, got_rows = [], []
+    with torch.no_grad():
+        for i, x in enumerate(xs):
+            s = streams[i % 2]
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                y = (m0, m1)[i % 2](x)
+                side.wait_stream(s)
+                with torch.cuda.stream(side):
+                    r, c = write_results_async(y, 80, 0.6, 0.5, cap=4096)
+                    got_rows.append((r.clone(), c.clone()))
+                y.record_stream(side)
+            got.append(y)
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    for (ra, ca), (rb, cb) in zip(want_rows, got_rows):
+        assert torch.equal(ca, cb)
+        assert torch.equal(ra[:int(ca[0])], rb[:int(cb[0])])
