@@ -31,6 +31,7 @@
 //
 // Limits: stride 1, pad 1, 3x3, Cin % 32 == 0, W <= 94.
 #include "conv_f16s3_common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace rtod {
@@ -56,6 +57,16 @@ template <typename T, int N> __device__ __forceinline__ void tie_regs(T (&r)[N])
 }
 
 __device__ __forceinline__ int band_swz(int row) { return (row >> 1) & 3; }
+
+// Diagnostic build only (make stamps -> librtod_stamps.so, -DRTOD_STAMPS): per-wave s_memtime attribution of the main
+// loop's phases, written to a device table the launcher prints.  The product library compiles none of it.
+#ifdef RTOD_STAMPS
+constexpr int STAMP_SLOTS = 8, STAMP_BLOCKS = 128, STAMP_WAVES = 16;
+__device__ unsigned long long g_band_stamps[STAMP_BLOCKS * STAMP_WAVES * (STAMP_SLOTS + 1)];
+#define RTOD_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ts_[i] += tn_ - tprev_; tprev_ = tn_; }
+#else
+#define RTOD_STAMP(i)
+#endif
 
 constexpr int BAND_MAX_W = 94;
 constexpr int BAND_EPI_BYTES = 65536;          // the launch allocates at least this much LDS: the epilogue's transpose tile
@@ -97,10 +108,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     const int nwg = grid_m * grid_n;
     int bid = blockIdx.x;
-    {
+    if (!a.xcd_by_n) {                                         // XCD x (= blockIdx % 8) takes a contiguous range of pixel tiles
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+    }                                                          // else: grid_n % 8 == 0, bn = bid % grid_n -> XCD = bn % 8
     const int bm = bid / grid_n, bn = bid - bm * grid_n;
 
     const int tid = KG == 1 ? (int)threadIdx.x : (int)threadIdx.x - kg * NT;   // thread index within the K group
@@ -266,6 +277,11 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             }
     };
 
+#ifdef RTOD_STAMPS
+    unsigned long long ts_[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart_ = tprev_;
+#endif
     // ---- prologue.  Issue order (vmcnt is in-order): band(0), B0, B1 | band written, B0 staged | B2, band(1)
     gload_band(0);
     gload_b(S0);
@@ -280,17 +296,22 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     band_age = 0;                                              // same issue pattern as at a chunk boundary: [B, B, band]
     __syncthreads();
 
+    RTOD_STAMP(0)                                              // 0: prologue
     int tap = 0, cc = 0;
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
     auto step = [&](int buf, BStage& Snext) {
         read_a(tap);
         wait_b(Snext);
+        RTOD_STAMP(1)                                          // 1: A reads issued + wait for the staged B set
         write_b(Snext, buf ^ 1);
         gload_b(Snext);
         __builtin_amdgcn_sched_barrier(0);
+        RTOD_STAMP(2)                                          // 2: B LDS writes + next loads issued
         compute(buf);
+        RTOD_STAMP(3)                                          // 3: B reads + MFMA issue
         __syncthreads();
+        RTOD_STAMP(4)                                          // 4: barrier
         if (++tap == 9) {
             tap = 0; ++cc;
             if (cc < n_cc) {                                   // uniform
@@ -299,6 +320,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                 gload_band(cc + 1);
                 band_age = 0;
                 __syncthreads();
+                RTOD_STAMP(5)                                  // 5: band replacement
             }
         }
     };
@@ -308,9 +330,18 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    RTOD_STAMP(6)                                              // 6: drain
 
     if (a.dbg & 4) return;
     conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, 16, f32x4, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+#ifdef RTOD_STAMPS
+    RTOD_STAMP(7)                                              // 7: epilogue
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {
+        unsigned long long* o = g_band_stamps + (blockIdx.x * STAMP_WAVES + (threadIdx.x >> 6)) * (STAMP_SLOTS + 1);
+        for (int i = 0; i < STAMP_SLOTS; ++i) o[i] = ts_[i];
+        o[STAMP_SLOTS] = tprev_ - tstart_;
+    }
+#endif
 }
 
 template <int BM, int BN, int NWM, int NWN, int MINW, int KG = 1>
@@ -318,6 +349,12 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
     if (a.Cin % (32 * KG)) { set_error("launch_conv_band: Cin=%d not a multiple of %d", a.Cin, 32 * KG); return RTOD_E_ARG; }
+    // Which operand should an XCD's L2 (4 MiB) keep?  Each XCD streams its workgroups' operands from memory once.
+    // Pixel-tile-major: an XCD reads 1/8 of the activations and ALL weights; channel-tile-major (possible when the N
+    // tiles split evenly over the 8 XCDs): 1/8 of the weights and all activations.  The deep 19x19 layers hold 18.9 MB of
+    // weights against 5.9 MB of activations: their main loop waited on weight loads 50 % longer than the other scales'.
+    ConvArgs ax = a;
+    ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
     const int main_bytes = KG * (4 * BN * 64 + 2 * (band_rows(BM, a.Wi) + 1) * 64);
     const int lds = main_bytes > BAND_EPI_BYTES ? main_bytes : BAND_EPI_BYTES;
     auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, KG>;
@@ -333,8 +370,26 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
             return hip_fail(hipGetLastError(), "conv_band_f16s3 LDS attribute");
         attr_done |= 1ull << (dev & 63);
     }
-    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, a, gm, gn);
-    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, a, gm, gn);
+    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
+#ifdef RTOD_STAMPS
+    {   // print the mean cycles per phase over the first blocks' waves (diagnostic build: synchronises)
+        static int printed = 0;
+        if (printed < 400 && hipDeviceSynchronize() == hipSuccess) {
+            static unsigned long long h[STAMP_BLOCKS * STAMP_WAVES * (STAMP_SLOTS + 1)];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_band_stamps), sizeof(h)) == hipSuccess) {
+                const int nb = gm * gn < STAMP_BLOCKS ? gm * gn : STAMP_BLOCKS, nw = NWM * NWN * KG;
+                double sum[STAMP_SLOTS + 1] = {0};
+                for (int b = 0; b < nb; ++b) for (int w = 0; w < nw; ++w) for (int i = 0; i <= STAMP_SLOTS; ++i)
+                    sum[i] += (double)h[(b * STAMP_WAVES + w) * (STAMP_SLOTS + 1) + i];
+                fprintf(stderr, "[stamps] band<%d,%d,%dx%d,k%d> W=%d Cin=%d Cout=%d tiles=%d steps=%d | cycles/wave:", BM, BN, NWM, NWN, KG, a.Wi, a.Cin, a.Cout, gm * gn, 9 * a.Cin / 32 / KG);
+                for (int i = 0; i <= STAMP_SLOTS; ++i) fprintf(stderr, " %s%.0f", i == STAMP_SLOTS ? "total=" : "", sum[i] / (nb * nw));
+                fprintf(stderr, "\n");
+                ++printed;
+            }
+        }
+    }
+#endif
     return hip_fail(hipGetLastError(), "conv_band_f16s3 launch");
 }
 

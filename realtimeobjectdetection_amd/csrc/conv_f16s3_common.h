@@ -106,8 +106,27 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
         bias2 = a.pw_bias[n2] * SPLIT_SCALE; inv2 = a.pw_inv_scale[n2] * SPLIT_SCALE;
     }
     const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
+    constexpr int GPR_ = BN / 8;                                          // 8-channel (16-byte) groups per row
+    constexpr int NG = (RG * GPR_ + NT - 1) / NT;                         // groups per thread and pass
 #pragma unroll 1
     for (int rg = 0; rg < BM; rg += RG) {
+        // residual operands of this pass: issued ahead of the transpose so that their latency (HBM / L2, ~2 us when
+        // waited for inside the store loop: in-kernel stamps showed the epilogue at 15 % of a 76x76 tile) overlaps the
+        // accumulator -> LDS phase and the barrier
+        f16x8 rq_h[RES ? NG : 1], rq_l[RES ? NG : 1];
+        if constexpr (RES) {
+            const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int g = tid + i * NT;
+                const int r = g / GPR_, c8 = (g - r * GPR_) * 8;
+                const int m = bm * BM + rg + r;
+                const bool ok = g < RG * GPR_ && m < M && bn * BN + c8 < a.Cout;
+                const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
+                rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
         if constexpr (KG == 2) {
             if (kg == 1 && wm * WM >= rg && wm * WM < rg + RG) {
 #pragma unroll
@@ -174,10 +193,12 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 }
             }
         } else {
-            constexpr int GPR = BN / 8;                                   // 8-channel (16-byte) groups per row
+            constexpr int GPR = GPR_;
             _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
-            const _Float16* rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
-            for (int g = tid; g < RG * GPR; g += NT) {
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int g = tid + gi * NT;
+                if (g >= RG * GPR) continue;
                 const int r = g / GPR, c8 = (g - r * GPR) * 8;
                 const int m = bm * BM + rg + r;
                 if (m >= M || bn * BN + c8 >= a.Cout) continue;
@@ -185,9 +206,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if constexpr (RES) {
-                    const _Float16* q = rh + (int64_t)m * 2 * a.res_ldc + c8;
-                    const f16x8 qh = *reinterpret_cast<const f16x8*>(q);
-                    const f16x8 ql = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
+                    const f16x8 qh = rq_h[gi], ql = rq_l[gi];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
                     if constexpr (PW) {                                   // the second GEMM reads the sum

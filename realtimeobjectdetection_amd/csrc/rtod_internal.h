@@ -62,6 +62,7 @@ struct ConvArgs {
     const float* inv_scale = nullptr;           // [Npad]: 1 / (2^e_n * SPLIT_SCALE)
     unsigned in_bytes = 0, w_bytes = 0;         // extents of the input buffer / one weight plane (buffer-load range check)
     int dbg = 0;                                // timing experiments only (RTOD_DBG_ZERO)
+    int xcd_by_n = 0;                           // split kernels: workgroup -> XCD by output-channel tile instead of by pixel tile (see launch_band)
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
     // split path, fused trailing 1x1 conv ("pointwise", conv_f16s3_common.h): the workgroup holds every channel of its
     // output pixels (Cout <= BN), so the next layer's 1x1 convolution runs as a second small GEMM in the epilogue
