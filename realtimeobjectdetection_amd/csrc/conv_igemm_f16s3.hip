@@ -26,9 +26,19 @@
 // advanced in scalar registers; loads are raw buffer loads whose per-lane voffset is
 // pixel-origin + tap offset, forced out of range (-> zeros) for padding taps and rows >= M.
 #include "conv_f16s3_common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace rtod {
+
+// Diagnostic build only (make stamps, -DRTOD_STAMPS): per-wave s_memtime attribution of the phases, as in conv_band_f16s3.hip.
+#ifdef RTOD_STAMPS
+constexpr int GSTAMP_SLOTS = 8, GSTAMP_BLOCKS = 128, GSTAMP_WAVES = 16;
+__device__ unsigned long long g_igemm_stamps[GSTAMP_BLOCKS * GSTAMP_WAVES * (GSTAMP_SLOTS + 1)];
+#define RTOD_GSTAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ts_[i] += tn_ - tprev_; tprev_ = tn_; }
+#else
+#define RTOD_GSTAMP(i)
+#endif
 
 template <int ASL, int BSL>
 struct StageRegs {
@@ -217,32 +227,55 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // one after (chunks >= nk are zero chunks); an odd nk costs one zero chunk of MFMAs.
     // vmcnt bookkeeping: loads complete in issue order; at every wait the older stage set has
     // LOADS_PER_STAGE loads outstanding and the younger set LOADS_PER_STAGE more behind them.
+#ifdef RTOD_STAMPS
+    unsigned long long ts_[GSTAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart_ = tprev_;
+#endif
     gload(S0);
     gload(S1);
     wait_stage(S0);
     lds_write(S0, 0);
     gload(S0);
     __syncthreads();
+    RTOD_GSTAMP(0)                                    // 0: prologue
     for (int t = 0; t < nk; t += 2) {
         read_a(0);                                    // chunk t
         wait_stage(S1);
+        RTOD_GSTAMP(1)                                // 1: A reads issued + wait for the staged set
         lds_write(S1, 1);                             // chunk t+1
         gload(S1);                                    // chunk t+3
         __builtin_amdgcn_sched_barrier(0);
+        RTOD_GSTAMP(2)                                // 2: LDS writes + loads issued
         compute(0);
+        RTOD_GSTAMP(3)                                // 3: B reads + MFMA issue
         __syncthreads();
+        RTOD_GSTAMP(4)                                // 4: barrier
         read_a(1);                                    // chunk t+1
         wait_stage(S0);
+        RTOD_GSTAMP(1)
         lds_write(S0, 0);                             // chunk t+2
         gload(S0);                                    // chunk t+4
         __builtin_amdgcn_sched_barrier(0);
+        RTOD_GSTAMP(2)
         compute(1);
+        RTOD_GSTAMP(3)
         __syncthreads();
+        RTOD_GSTAMP(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
+    RTOD_GSTAMP(5)                                    // 5: drain
 
     if (a.dbg & 4) return;                            // timing experiment: no epilogue
     conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE, 16, f32x4>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
+#ifdef RTOD_STAMPS
+    RTOD_GSTAMP(6)                                    // 6: epilogue
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < GSTAMP_BLOCKS) {
+        unsigned long long* o = g_igemm_stamps + (blockIdx.x * GSTAMP_WAVES + (threadIdx.x >> 6)) * (GSTAMP_SLOTS + 1);
+        for (int i = 0; i < GSTAMP_SLOTS; ++i) o[i] = ts_[i];
+        o[GSTAMP_SLOTS] = tprev_ - tstart_;
+    }
+#endif
 }
 
 static const ConvVariantInfo kHVariants[HV_COUNT] = {
@@ -280,6 +313,25 @@ static int launch_h(const ConvArgs& a, hipStream_t s) {
     else if (a.dec.enabled) hipLaunchKernelGGL(k_dec, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     else if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NT), 0, s, a, gm, gn);
+#ifdef RTOD_STAMPS
+    {
+        static int printed = 0;
+        if (printed < 400 && hipDeviceSynchronize() == hipSuccess) {
+            static unsigned long long h[GSTAMP_BLOCKS * GSTAMP_WAVES * (GSTAMP_SLOTS + 1)];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_igemm_stamps), sizeof(h)) == hipSuccess) {
+                const int nb = gm * gn < GSTAMP_BLOCKS ? gm * gn : GSTAMP_BLOCKS, nw = NWM * NWN;
+                double sum[GSTAMP_SLOTS + 1] = {0};
+                for (int b = 0; b < nb; ++b) for (int w = 0; w < nw; ++w) for (int i = 0; i <= GSTAMP_SLOTS; ++i)
+                    sum[i] += (double)h[(b * GSTAMP_WAVES + w) * (GSTAMP_SLOTS + 1) + i];
+                fprintf(stderr, "[stamps] igemm<%d,%d,%dx%d> k=%d s=%d W=%d Cin=%d Cout=%d tiles=%d steps=%d epi=%d | cycles/wave:", BM, BN, NWM, NWN, a.kh, a.stride,
+                        a.Wo, a.Cin, a.Cout, gm * gn, a.Kpad / 32, a.pw_wh ? 3 : (a.dec.enabled ? 2 : (a.res ? 1 : 0)));
+                for (int i = 0; i <= GSTAMP_SLOTS; ++i) fprintf(stderr, " %s%.0f", i == GSTAMP_SLOTS ? "total=" : "", sum[i] / (nb * nw));
+                fprintf(stderr, "\n");
+                ++printed;
+            }
+        }
+    }
+#endif
     return hip_fail(hipGetLastError(), "conv_igemm_f16s3 launch");
 }
 
