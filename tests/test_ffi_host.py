@@ -134,3 +134,27 @@ def test_darknet_host_class_without_gpu(tmp_path):
     assert np.array_equal(m.weight_stream(), w)
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 3, 416, 416))
+
+
+def test_fused_pointwise_accounting_in_split_plans():
+    """precision f16s3: YOLOv3's layer 2 (1x1, 64 -> 32) runs in layer 1's epilogue; its FLOPs move to the host launch and its
+    own launch entry is empty, so the per-launch table still sums to the network's FLOPs (host-only: no device needed)."""
+    rc, h = _plan(cfgs.yolov3_cfg(), 608)
+    assert rc == 0
+    ir = build_ir(parse_cfg_text(cfgs.yolov3_cfg()), 608)
+    lib = _ffi.lib()
+    assert lib.rtod_plan_set_precision(h, 1) == 0, _ffi.last_error()
+    info = _ffi.PlanInfo()
+    assert lib.rtod_plan_get_info(h, C.byref(info)) == 0
+    flops, hosts, empty = 0, [], []
+    for i in range(info.n_launches):
+        li = _ffi.LaunchInfo()
+        assert lib.rtod_plan_get_launch(h, i, C.byref(li)) == 0
+        flops += li.flops_per_frame
+        if li.fused_pointwise:
+            hosts.append(li.layer)
+        if li.kind == 0 and li.flops_per_frame == 0:
+            empty.append(li.layer)
+    assert flops == ir.conv_flops
+    assert hosts == [1] and empty == [2]
+    lib.rtod_plan_destroy(h)
