@@ -25,9 +25,9 @@
 // chunk swizzle (row >> 1) & 3 keeps that read conflict-free for EVERY band shift (tools/lds_bank_sim.py).
 //
 // A layer that this kernel supports always runs on it, at every batch size, whatever tile autotune picks:
-// all tiles accumulate a pixel's K products in the same order, so the frame-independence guarantee (bitwise
-// equal outputs for a frame whatever batch it rides in) holds although 16x16x32 and the generic kernel's
-// 32x32x16 round differently.
+// all tiles accumulate a pixel's K products in the same order (split-K is decided by the layer's shape, never by
+// the batch), so the frame-independence guarantee (bitwise equal outputs for a frame whatever batch it rides in)
+// holds under autotuning.
 //
 // Limits: stride 1, pad 1, 3x3, Cin % 32 == 0, W <= 94.
 #include "conv_f16s3_common.h"
@@ -333,7 +333,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     RTOD_STAMP(6)                                              // 6: drain
 
     if (a.dbg & 4) return;
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, 16, f32x4, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {

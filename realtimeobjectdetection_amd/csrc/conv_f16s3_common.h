@@ -5,7 +5,6 @@
 namespace rtod {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -59,16 +58,14 @@ constexpr int epi_row_group(int bm, int wm, int rg_max) {
 
 // ---- common epilogue: scale / bias / leaky, LDS transpose, then split-format store (+ residual) or head decode.
 // `smem` is the kernel's whole LDS allocation (dead after the main loop, which must end on a barrier).
-// MT = MFMA tile edge: 32 (v_mfma_f32_32x32x16_f16: lane holds column lane%32, rows (e&3) + 8(e>>2) + 4(lane/32)) or
-// 16 (v_mfma_f32_16x16x32_f16: column lane%16, rows e + 4(lane/16)).
+// Accumulators are v_mfma_f32_16x16x32_f16 tiles: lane holds column lr = lane%16, rows e + 4*lh, lh = lane/16.
 // KG = 2 (in-workgroup split-K, conv_band_f16s3.hip): NT counts both wave groups, `tid` is the workgroup-wide thread
 // index, wm / wn are positions inside the group `kg`; group 1 deposits its raw accumulators in the tile first and
 // group 0 adds its own before scale / bias / activation.
-template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int MT = 32, typename AccT = f32x16, int KG = 1>
-__device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&acc)[WM / MT][WN / MT], unsigned char* smem,
+template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int KG = 1>
+__device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem,
                                                     int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M, int kg = 0) {
-    constexpr int TM = WM / MT, TN = WN / MT, NE = MT * MT / 64;
-    static_assert(sizeof(AccT) == NE * 4, "accumulator type / MFMA tile");
+    constexpr int MT = 16, TM = WM / MT, TN = WN / MT, NE = 4;
     constexpr bool PW = EPI == EPI_SPLIT_PW || EPI == EPI_SPLIT_RES_PW;
     constexpr bool RES = EPI == EPI_SPLIT_RES || EPI == EPI_SPLIT_RES_PW;
     // fused pointwise conv: the transpose tile doubles as the A operand of the second GEMM (row stride + 4 floats: the
@@ -135,7 +132,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int e = 0; e < NE; ++e)
-                            T[(wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh) * TS + wn * WN + j * MT + lr] = acc[i][j][e];
+                            T[(wm * WM - rg + i * MT + e + 4 * lh) * TS + wn * WN + j * MT + lr] = acc[i][j][e];
             }
             __syncthreads();
         }
@@ -150,7 +147,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, AccT (&ac
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
-                        const int rl = wm * WM - rg + i * MT + (MT == 32 ? (e & 3) + 8 * (e >> 2) : e) + 4 * lh;
+                        const int rl = wm * WM - rg + i * MT + e + 4 * lh;
                         float s = acc[i][j][e];
                         if constexpr (KG == 2) s += T[rl * TS + nl];
                         float v = s * inv + bias;

@@ -267,7 +267,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     RTOD_GSTAMP(5)                                    // 5: drain
 
     if (a.dbg & 4) return;                            // timing experiment: no epilogue
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE, 16, f32x4>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
+    conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
 #ifdef RTOD_STAMPS
     RTOD_GSTAMP(6)                                    // 6: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < GSTAMP_BLOCKS) {

@@ -88,7 +88,7 @@ const ConvVariantInfo& conv_f16s3_variant_info(int v);
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 // 3x3 stride-1 pad-1 convs with an LDS-resident input band (conv_band_f16s3.hip); weights in band K order
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
-// A layer the band kernel supports ALWAYS runs on it (16x16x32 MFMA; the generic kernel's 32x32x16 rounds differently, and
+// A layer the band kernel supports ALWAYS runs on it (its split-K layers sum in a different order than the generic kernel, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
 constexpr int BAND_MODES = 9;              // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
                                            // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2
