@@ -95,28 +95,13 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=25.0):
                       % (iters, res, res, batch, torch.__version__, cores)}
 
 
-def rocprof_kernel_name(tile_name, epi):
-    """'conv_igemm_f16s3<128x128,w64x64>' + epilogue id -> the demangled name rocprofv3 prints."""
-    import re
-    mb = re.match(r"conv_band_f16s3<(\d+)x(\d+),(\d)x(\d)(,k2)?>", tile_name)
-    if mb:
-        bm, bn, nwm, nwn = [int(v) for v in mb.groups()[:4]]
-        minw = {(192, 128): 3, (128, 128): 4 if nwm == 4 else 2}.get((bm, bn), 4)     # launch_conv_band_f16s3's MINW per mode
-        return "void rtod::conv_band_f16s3_kernel<%d, %d, %d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (
-            bm, bn, nwm, nwn, minw, epi, 2 if mb.group(5) else 1)
-    mh = re.match(r"conv_igemm_f16s3<(\d+)x(\d+),(\d)x(\d)>", tile_name)
-    if mh:
-        bm, bn, nwm, nwn = [int(v) for v in mh.groups()]
-        minw = IGEMM_MINW[(bm, bn, nwm, nwn)]
-        return "void rtod::conv_igemm_f16s3_kernel<%d, %d, %d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, nwm, nwn, minw, epi)
-    m = re.match(r"conv_igemm_f32<(\d+)x(\d+),w(\d+)x(\d+)>", tile_name)
-    bm, bn, wm, wn = [int(v) for v in m.groups()]
-    return "void rtod::conv_igemm_f32_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)" % (bm, bn, wm, wn)
-
-
-# launch_conv_f16s3's MINW template argument per tile (conv_igemm_f16s3.hip)
-IGEMM_MINW = {(128, 128, 2, 2): 2, (128, 64, 2, 2): 3, (64, 64, 2, 2): 4, (64, 128, 2, 2): 3, (256, 128, 4, 2): 2, (128, 256, 2, 4): 2,
-              (128, 128, 4, 2): 4, (128, 64, 4, 2): 4, (256, 128, 8, 2): 4, (192, 128, 4, 2): 3, (96, 128, 2, 4): 4, (192, 128, 6, 2): 3}
+def rocprof_kernel_name(variant, epi):
+    """Exact kernel instantiation name rocprofv3 prints for a conv launch (built next to the launch switch in csrc)."""
+    import ctypes as C
+    from realtimeobjectdetection_amd import _ffi
+    buf = C.create_string_buffer(256)
+    _ffi.check(_ffi.lib().rtod_conv_kernel_name(int(variant), int(epi), buf, 256))
+    return buf.value.decode()
 
 
 def roofline_from_launches(model, x, steps):
@@ -138,7 +123,7 @@ def roofline_from_launches(model, x, steps):
         # group by the exact kernel instantiation rocprofv3 reports (tile variant + epilogue)
         name = lib.rtod_conv_variant_name(li.variant).decode()
         epi = 2 if li.fused_decode else ((4 if li.fused_residual else 3) if li.fused_pointwise else (1 if li.fused_residual else 0))
-        kname = rocprof_kernel_name(name, epi)
+        kname = rocprof_kernel_name(li.variant, epi)
         g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "tile": name})
         g["ms"] += float(ms); g["flops"] += float(li.flops_per_frame) * B; g["launches"] += 1
     dom = max(groups.items(), key=lambda kv: kv[1]["ms"])

@@ -81,6 +81,9 @@ int rtod_plan_get_launch(const rtod_plan* plan, int index, rtod_launch_info* out
 /* JSON description of the resolved layer IR (tests compare it with the Python IR / reference). */
 int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* needed);
 const char* rtod_conv_variant_name(int variant);
+/* Demangled name of the kernel instantiation a launch runs (what rocprofv3 --kernel-trace prints): variant from
+ * rtod_launch_info, epilogue 0 plain, 1 fused shortcut, 2 fused head decode, 3 / 4 = 0 / 1 with a fused pointwise conv. */
+int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len);
 /* Arithmetic of the convolutions (call before rtod_plan_load_weights):
  *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-level fmaf chains, the parity anchor;
  *   1  split-precision f16 MFMA: a*w ~= ah*wh + ah*wl + al*wh with fp32 accumulation (22-bit

@@ -98,6 +98,16 @@ const char* rtod_conv_variant_name(int variant) {
     return conv_variant_info(variant).name;
 }
 
+int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len) {
+    if (!buf || len == 0) { set_error("conv_kernel_name: null buffer"); return RTOD_E_ARG; }
+    int n = -1;
+    if (variant >= 100 + BAND_VARIANT_BASE) n = conv_band_kernel_name(variant - 100 - BAND_VARIANT_BASE, epilogue, buf, len);
+    else if (variant >= 100) n = conv_f16s3_kernel_name(variant - 100, epilogue, buf, len);
+    else n = conv_f32_kernel_name(variant, buf, len);
+    if (n < 0 || (size_t)n >= len) { set_error("conv_kernel_name: unknown variant %d or buffer too small", variant); return RTOD_E_ARG; }
+    return RTOD_OK;
+}
+
 int rtod_plan_set_precision(rtod_plan* plan, int mode) {
     if (!plan || (mode != 0 && mode != 1)) { set_error("set_precision: mode must be 0 (fp32) or 1 (f16 split)"); return RTOD_E_ARG; }
     if (plan->p.d_weights) { set_error("set_precision: must be called before rtod_plan_load_weights"); return RTOD_E_STATE; }

@@ -407,17 +407,25 @@ bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && w_in <= BAND_MAX_W;
 }
 
-static const ConvVariantInfo kBandModes[BAND_MODES] = {
-    {128, 128, "conv_band_f16s3<128x128,4x2>"},
-    {128, 64, "conv_band_f16s3<128x64,4x2>"},
-    {192, 128, "conv_band_f16s3<192x128,4x2>"},
-    {192, 128, "conv_band_f16s3<192x128,6x2>"},
-    {96, 128, "conv_band_f16s3<96x128,2x4>"},
-    {128, 128, "conv_band_f16s3<128x128,2x2>"},
-    {64, 128, "conv_band_f16s3<64x128,2x4>"},
-    {96, 128, "conv_band_f16s3<96x128,2x4,k2>"},
-    {128, 128, "conv_band_f16s3<128x128,4x2,k2>"},
-};
+// One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
+//   X(mode, BM, BN, waves along M, waves along N, MINW, K groups, name suffix)
+#define RTOD_BAND_TILES(X) \
+    X(0, 128, 128, 4, 2, 4, 1, "") X(1, 128, 64, 4, 2, 4, 1, "") X(2, 192, 128, 4, 2, 3, 1, "") X(3, 192, 128, 6, 2, 3, 1, "") \
+    X(4, 96, 128, 2, 4, 4, 1, "") X(5, 128, 128, 2, 2, 2, 1, "") X(6, 64, 128, 2, 4, 4, 1, "") \
+    X(7, 96, 128, 2, 4, 4, 2, ",k2") X(8, 128, 128, 4, 2, 4, 2, ",k2")
+
+#define RTOD_X_INFO(mode, bm, bn, nwm, nwn, minw, kg, sfx) {bm, bn, "conv_band_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
+static const ConvVariantInfo kBandModes[BAND_MODES] = { RTOD_BAND_TILES(RTOD_X_INFO) };
+#undef RTOD_X_INFO
+
+int conv_band_kernel_name(int mode, int epi, char* buf, size_t len) {
+#define RTOD_X_NAME(m, bm, bn, nwm, nwn, minw, kg, sfx) \
+    if (mode == m) return snprintf(buf, len, "void rtod::conv_band_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #kg ">(rtod::ConvArgs, int, int)", epi);
+    RTOD_BAND_TILES(RTOD_X_NAME)
+#undef RTOD_X_NAME
+    return -1;
+}
+
 const ConvVariantInfo& conv_band_mode_info(int mode) { return kBandModes[mode < 0 || mode >= BAND_MODES ? 0 : mode]; }
 
 int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
@@ -434,15 +442,9 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
     switch (mode) {
-        case 0: return launch_band<128, 128, 4, 2, 4>(a, s);
-        case 1: return launch_band<128, 64, 4, 2, 4>(a, s);
-        case 2: return launch_band<192, 128, 4, 2, 3>(a, s);
-        case 3: return launch_band<192, 128, 6, 2, 3>(a, s);
-        case 4: return launch_band<96, 128, 2, 4, 4>(a, s);
-        case 5: return launch_band<128, 128, 2, 2, 2>(a, s);
-        case 6: return launch_band<64, 128, 2, 4, 4>(a, s);
-        case 7: return launch_band<96, 128, 2, 4, 4, 2>(a, s);
-        case 8: return launch_band<128, 128, 4, 2, 4, 2>(a, s);
+#define RTOD_X_CASE(m, bm, bn, nwm, nwn, minw, kg, sfx) case m: return launch_band<bm, bn, nwm, nwn, minw, kg>(a, s);
+        RTOD_BAND_TILES(RTOD_X_CASE)
+#undef RTOD_X_CASE
     }
     set_error("launch_conv_band: mode %d unsupported", mode);
     return RTOD_E_ARG;

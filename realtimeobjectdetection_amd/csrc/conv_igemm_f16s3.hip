@@ -278,20 +278,25 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #endif
 }
 
-static const ConvVariantInfo kHVariants[HV_COUNT] = {
-    {128, 128, "conv_igemm_f16s3<128x128,2x2>"},
-    {128, 64, "conv_igemm_f16s3<128x64,2x2>"},
-    {64, 64, "conv_igemm_f16s3<64x64,2x2>"},
-    {64, 128, "conv_igemm_f16s3<64x128,2x2>"},
-    {256, 128, "conv_igemm_f16s3<256x128,4x2>"},
-    {128, 256, "conv_igemm_f16s3<128x256,2x4>"},
-    {128, 128, "conv_igemm_f16s3<128x128,4x2>"},
-    {128, 64, "conv_igemm_f16s3<128x64,4x2>"},
-    {256, 128, "conv_igemm_f16s3<256x128,8x2>"},
-    {192, 128, "conv_igemm_f16s3<192x128,4x2>"},
-    {96, 128, "conv_igemm_f16s3<96x128,2x4>"},
-    {192, 128, "conv_igemm_f16s3<192x128,6x2>"},
-};
+// One list drives the tile table, the launch switch and the kernel names rocprofv3 prints:
+//   X(variant id, BM, BN, waves along M, waves along N, MINW)
+#define RTOD_IGEMM_TILES(X) \
+    X(HV_128x128, 128, 128, 2, 2, 2) X(HV_128x64, 128, 64, 2, 2, 3) X(HV_64x64, 64, 64, 2, 2, 4) X(HV_64x128, 64, 128, 2, 2, 3) \
+    X(HV_256x128, 256, 128, 4, 2, 2) X(HV_128x256, 128, 256, 2, 4, 2) X(HV_128x128_8W, 128, 128, 4, 2, 4) X(HV_128x64_8W, 128, 64, 4, 2, 4) \
+    X(HV_256x128_16W, 256, 128, 8, 2, 4) X(HV_192x128_8W, 192, 128, 4, 2, 3) X(HV_96x128_8W, 96, 128, 2, 4, 4) X(HV_192x128_12W, 192, 128, 6, 2, 3)
+
+#define RTOD_X_INFO(id, bm, bn, nwm, nwn, minw) {bm, bn, "conv_igemm_f16s3<" #bm "x" #bn "," #nwm "x" #nwn ">"},
+static const ConvVariantInfo kHVariants[HV_COUNT] = { RTOD_IGEMM_TILES(RTOD_X_INFO) };
+#undef RTOD_X_INFO
+
+// demangled name of the instantiation (what rocprofv3 --kernel-trace reports), for bench.py / profiles
+int conv_f16s3_kernel_name(int variant, int epi, char* buf, size_t len) {
+#define RTOD_X_NAME(id, bm, bn, nwm, nwn, minw) \
+    if (variant == id) return snprintf(buf, len, "void rtod::conv_igemm_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d>(rtod::ConvArgs, int, int)", epi);
+    RTOD_IGEMM_TILES(RTOD_X_NAME)
+#undef RTOD_X_NAME
+    return -1;
+}
 
 const ConvVariantInfo& conv_f16s3_variant_info(int v) { return kHVariants[v < 0 || v >= HV_COUNT ? 0 : v]; }
 
@@ -358,18 +363,9 @@ int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
     switch (variant) {
-        case HV_128x128: return launch_h<128, 128, 2, 2, 2>(a, s);
-        case HV_128x64: return launch_h<128, 64, 2, 2, 3>(a, s);
-        case HV_64x64: return launch_h<64, 64, 2, 2, 4>(a, s);
-        case HV_64x128: return launch_h<64, 128, 2, 2, 3>(a, s);
-        case HV_256x128: return launch_h<256, 128, 4, 2, 2>(a, s);
-        case HV_128x256: return launch_h<128, 256, 2, 4, 2>(a, s);
-        case HV_128x128_8W: return launch_h<128, 128, 4, 2, 4>(a, s);
-        case HV_128x64_8W: return launch_h<128, 64, 4, 2, 4>(a, s);
-        case HV_256x128_16W: return launch_h<256, 128, 8, 2, 4>(a, s);
-        case HV_192x128_8W: return launch_h<192, 128, 4, 2, 3>(a, s);
-        case HV_96x128_8W: return launch_h<96, 128, 2, 4, 4>(a, s);
-        case HV_192x128_12W: return launch_h<192, 128, 6, 2, 3>(a, s);
+#define RTOD_X_CASE(id, bm, bn, nwm, nwn, minw) case id: return launch_h<bm, bn, nwm, nwn, minw>(a, s);
+        RTOD_IGEMM_TILES(RTOD_X_CASE)
+#undef RTOD_X_CASE
     }
     set_error("launch_conv_f16s3: unknown variant %d", variant);
     return RTOD_E_ARG;

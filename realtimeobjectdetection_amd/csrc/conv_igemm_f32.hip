@@ -17,6 +17,7 @@
 // an 8-wide k group the two lane halves take k = {0..3} and {4..7} so one ds_read_b128 feeds four
 // MFMAs; the chain order is a fixed permutation of k.
 #include "rtod_internal.h"
+#include <cstdio>
 
 namespace rtod {
 
@@ -198,6 +199,12 @@ static const ConvVariantInfo kVariants[CV_COUNT] = {
 };
 
 const ConvVariantInfo& conv_variant_info(int v) { return kVariants[v < 0 || v >= CV_COUNT ? 0 : v]; }
+
+int conv_f32_kernel_name(int variant, char* buf, size_t len) {          // demangled instantiation name (rocprofv3)
+    static const int t[CV_COUNT][4] = {{128, 128, 64, 64}, {128, 64, 64, 32}, {64, 64, 32, 32}, {128, 32, 32, 32}};   // launch_conv's template arguments
+    if (variant < 0 || variant >= CV_COUNT) return -1;
+    return snprintf(buf, len, "void rtod::conv_igemm_f32_kernel<%d, %d, %d, %d>(rtod::ConvArgs, int, int)", t[variant][0], t[variant][1], t[variant][2], t[variant][3]);
+}
 
 template <int BM, int BN, int WM, int WN>
 static int launch_t(const ConvArgs& a, hipStream_t s) {

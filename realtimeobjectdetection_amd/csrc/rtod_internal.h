@@ -81,10 +81,12 @@ constexpr float ACT_SCALE_F16S3 = SPLIT_SCALE;
 enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, CV_COUNT };
 struct ConvVariantInfo { int bm, bn; const char* name; };
 const ConvVariantInfo& conv_variant_info(int v);
+int conv_f32_kernel_name(int variant, char* buf, size_t len);
 int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
 enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_256x128 = 4, HV_128x256 = 5, HV_128x128_8W = 6, HV_128x64_8W = 7, HV_256x128_16W = 8,
                       HV_192x128_8W = 9, HV_96x128_8W = 10, HV_192x128_12W = 11, HV_COUNT };
 const ConvVariantInfo& conv_f16s3_variant_info(int v);
+int conv_f16s3_kernel_name(int variant, int epi, char* buf, size_t len);      // demangled instantiation name (rocprofv3)
 int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 // 3x3 stride-1 pad-1 convs with an LDS-resident input band (conv_band_f16s3.hip); weights in band K order
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
@@ -97,6 +99,7 @@ int conv_band_layer_kg(int cin, int h, int w);
 bool conv_band_mode_valid(int mode, int cin, int h, int w);
 int conv_band_default_mode(int cin, int h, int w);
 const ConvVariantInfo& conv_band_mode_info(int mode);
+int conv_band_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_band_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the band kernel: BAND_VARIANT_BASE + mode
 
