@@ -434,3 +434,34 @@ def test_odd_resolution_and_batch_vs_oracle(tmp_path_factory, res, batch):
         dgn = dg.cpu().numpy(); dwn = dw.numpy() if hasattr(dw, "numpy") else np.asarray(dw)
         # near-threshold candidates may flip between the two arithmetics; require near-identical detection sets
         assert abs(len(dgn) - len(dwn)) <= max(2, len(dwn) // 50)
+
+
+@pytest.mark.parametrize("classes", [20, 1])
+def test_other_class_counts_vs_oracle(tmp_path_factory, classes):
+    """cfgs with classes != 80 (VOC's 20, a single class): head convs with 75 / 18 filters, [B,N,25] / [B,N,6] rows, NMS over
+    that many class columns — the reference reads all of this from the cfg (src/darknet.py:239, 260)."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd.util import write_results
+    res, batch = 320, 2
+    cfg_text = cfgs.yolov3_cfg(classes=classes)
+    d = tmp_path_factory.mktemp("cls%d" % classes)
+    m = Darknet(cfgs.write_cfg(str(d / "v3.cfg"), cfg_text), True).eval()
+    m.net_info["height"] = res
+    m.precision = "f16s3"
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    m.load_weight_stream(w)
+    ref.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(batch, res, seed=5))
+    with torch.no_grad():
+        want = ref.forward(x)
+        got = m(x.cuda())
+    assert tuple(got.shape) == tuple(want.shape) == (batch, 3 * (10 * 10 + 20 * 20 + 40 * 40), 5 + classes)
+    assert rel_err(got.cpu().numpy(), want.numpy()).max() <= TOL
+    # NMS on identical inputs is bit-exact for any class count
+    dw = O.write_results(want, classes, 0.5, 0.4)
+    dg = write_results(want.cuda(), classes, 0.5, 0.4)
+    if isinstance(dw, int):
+        assert isinstance(dg, int) and dg == 0
+    else:
+        assert torch.equal(dg.cpu(), dw if isinstance(dw, torch.Tensor) else torch.from_numpy(np.asarray(dw)))
