@@ -4,24 +4,35 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--res 608] [--batch 8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-``Darknet.forward`` (78 HIP launches) + ``write_results`` (filter, sort, NMS; 3 launches) and, for
-N > 1, the fixed-capacity RCCL all-gather of the detections.  One process per GPU; frames are
-sharded (weak scaling: every rank runs its own ``--batch`` frames), no collective on the data path
-except that final gather.  Rank 0 prints ONE JSON line.
+Both launch forms work: started plainly with ``--gpus N > 1`` (no WORLD_SIZE in the environment) this process starts N
+child ranks itself — before it makes any GPU call — relays rank 0's JSON line and exits non-zero if a rank fails.
 
-Extra objects in the line:
-  roofline      dominant kernel = the conv implicit-GEMM instantiation with the largest total time.
-                achieved = algorithmic conv FLOPs of its launches / their summed duration, measured
-                with a hipEvent pair around every launch on the launch stream (rtod_forward_timed)
-                in an instrumented replay of the timed steps right after the timed region.
-                peak = 157.3 TFLOP/s (exact-fp32 MFMA, MI355X_MICROARCH.md).
-  cpu_baseline  the oracle (oracle/darknet_ref.py: the reference's PyTorch-CPU op sequence + NMS)
-                timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+``Darknet.forward`` (one launch list on one HIP stream) + ``write_results`` (filter, sort, NMS; 3 launches) and, for
+N > 1, the fixed-capacity RCCL all-gather of the detections (shard.FixedGather).  One process per GPU; frames are
+sharded (weak scaling: every rank runs its own ``--batch`` frames), no collective on the data path except that final
+gather.  Rank 0 prints ONE JSON line.
+
+What the numbers in the line are (all measured in this run, same plans, same inputs):
+  value         K steps between barrier + device-synchronise pairs, ``--inflight`` batches in flight (default 2: steps
+                alternate over two plans on two HIP streams), ``write_results_async`` (device-side counts, no host sync)
+                on a third stream.  The throughput-serving schedule; the metric string says so.
+  single_stream one batch in flight: forward i+1 starts after forward i (write_results_async still on its own stream).
+  dropin_api    the reference's calling sequence verbatim (detect.py:62-70): ``y = model(x)``;
+                ``write_results(y, 80, conf, nms)`` returning a new [D,8] tensor — one plan, one stream, the host
+                synchronisation of write_results inside every step.
+  roofline      dominant kernel = the conv instantiation with the largest total time.  achieved = algorithmic conv FLOPs
+                of its launches / their summed duration, from a hipEvent pair around every launch on the launch stream
+                (rtod_forward_timed) in an instrumented single-stream replay right after the timed region.
+  cpu_baseline  the oracle (oracle/darknet_ref.py: the reference's PyTorch-CPU op sequence + NMS) timed on
+                this box's host cores on a bounded sample (rank 0, N = 1 only): all cores and one thread, forward and
+                NMS separately.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -29,14 +40,67 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0        # dense f16/bf16 MFMA; the split kernel issues 3 products per algorithmic MAC
 HBM_PEAK_GBS = 8000.0
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--res", type=int, default=608)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--conf", type=float, default=0.6)
+    ap.add_argument("--nms", type=float, default=0.5)
+    ap.add_argument("--precision", default="f16s3", choices=["fp32", "f16s3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-nms", action="store_true", help="run write_results on the forward's stream (no overlap with the next batch)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight: steps alternate over N plans (own activation arena) on N HIP streams, so one batch's "
+                         "partial rounds, prologues and epilogues overlap the other's kernels; 1 = strictly sequential forwards")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ self-launch (N > 1)
+def self_launch(args):
+    """Start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1).
+    Runs BEFORE this process touches the GPU: it imports nothing that initialises HIP and never becomes a rank itself."""
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0 owns stdout (the one JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            alive.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+                for q in alive:
+                    procs[q].terminate()                    # exact PIDs this process started
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ model / baselines
 def build_model(res, device, max_batch, precision):
     from realtimeobjectdetection_amd import cfgs, synth
     from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
@@ -71,28 +135,57 @@ def host_cpu_share():
     return max(1, min(n, int(os.environ.get("RTOD_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=25.0):
-    """Oracle forward + write_results on the host cores, bounded sample."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=14.0):
+    """Oracle forward and write_results on the host cores, bounded: all cores on the bench batch
+    (1 warm-up, up to 10 timed iterations inside ``budget_s``) and one thread on a single frame."""
+    import torch
     from realtimeobjectdetection_amd import synth
     from oracle import darknet_ref as O
     cores = host_cpu_share()
-    torch.set_num_threads(cores)
     ref = O.RefDarknet(cfg_text, res)
     ref.load_weight_stream(w)
     x = torch.from_numpy(synth.synth_frames(batch, res))
+    out = {}
     with torch.no_grad():
+        torch.set_num_threads(cores)
         t0 = time.perf_counter()
         y = ref.forward(x)                      # warm-up (also sizes the sample)
         warm = time.perf_counter() - t0
-        iters = int(max(1, min(4, budget_s // max(warm, 1e-3) - 1)))
-        t0 = time.perf_counter()
+        iters = int(max(1, min(10, budget_s // max(warm, 1e-3))))
+        tf = tn = 0.0
         for _ in range(iters):
+            t0 = time.perf_counter()
             y = ref.forward(x)
+            t1 = time.perf_counter()
             O.write_results(y, 80, conf, nms)
-        dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d x (yolov3 %dx%d batch %d forward + write_results), torch %s CPU ops, %d threads"
-                      % (iters, res, res, batch, torch.__version__, cores)}
+            t2 = time.perf_counter()
+            tf += t1 - t0; tn += t2 - t1
+        out = {"value": round(batch * iters / (tf + tn), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d x (yolov3 %dx%d batch %d forward + write_results) after 1 warm-up, torch %s CPU ops, %d threads"
+                         % (iters, res, res, batch, torch.__version__, cores),
+               "forward_s_per_batch": round(tf / iters, 4), "write_results_s_per_batch": round(tn / iters, 4),
+               "cpu_model": cpu_model_name(), "host_cores_visible": os.cpu_count()}
+        torch.set_num_threads(1)
+        x1 = x[:1].contiguous()
+        t0 = time.perf_counter()
+        y1 = ref.forward(x1)
+        t1 = time.perf_counter()
+        O.write_results(y1, 80, conf, nms)
+        t2 = time.perf_counter()
+        out["one_thread"] = {"value": round(1.0 / (t2 - t0), 4), "unit": "frames/s", "forward_s": round(t1 - t0, 4),
+                             "write_results_s": round(t2 - t1, 4), "sample": "1 x (batch 1 forward + write_results), 1 thread, no warm-up"}
+        torch.set_num_threads(cores)
+    return out
 
 
 def rocprof_kernel_name(variant, epi):
@@ -105,8 +198,8 @@ def rocprof_kernel_name(variant, epi):
 
 
 def roofline_from_launches(model, x, steps):
-    """Instrumented replay: hipEvent pair around every launch; group conv launches by tile variant."""
-    import ctypes as C
+    """Instrumented replay: hipEvent pair around every launch; group conv launches by kernel instantiation."""
+    import numpy as np
     from realtimeobjectdetection_amd import _ffi
     infos = model.launch_infos()
     B = x.size(0)
@@ -124,8 +217,9 @@ def roofline_from_launches(model, x, steps):
         name = lib.rtod_conv_variant_name(li.variant).decode()
         epi = 2 if li.fused_decode else ((4 if li.fused_residual else 3) if li.fused_pointwise else (1 if li.fused_residual else 0))
         kname = rocprof_kernel_name(li.variant, epi)
-        g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "tile": name})
+        g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "tile": name})
         g["ms"] += float(ms); g["flops"] += float(li.flops_per_frame) * B; g["launches"] += 1
+        g["bytes"] += float(li.bytes_per_frame) * B + float(li.weight_bytes)
     dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
     name, g = dom
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
@@ -135,6 +229,10 @@ def roofline_from_launches(model, x, steps):
                   "tflops": round(float(li.flops_per_frame) * B / (float(ms) * 1e-3) / 1e12, 2) if li.kind == 0 and ms > 0 else None,
                   "gbs": round((float(li.bytes_per_frame) * B + li.weight_bytes) / (float(ms) * 1e-3) / 1e9, 1) if ms > 0 else None}
                  for li, ms in zip(infos, tot)]
+    # the pointwise (1x1, stride 1) group: HBM-bound by algorithmic bytes (north star: achieved GB/s on the 1x1 convs)
+    pw = [(li, ms) for li, ms in zip(infos, tot) if li.kind == 0 and li.ksize == 1 and li.flops_per_frame > 0]
+    pw_ms = sum(float(ms) for _, ms in pw)
+    pw_bytes = sum(float(li.bytes_per_frame) * B + float(li.weight_bytes) for li, _ in pw)
     split = "f16s3" in name
     peak = round(PEAK_F16_MFMA_TFLOPS / 3.0, 1) if split else PEAK_FP32_MFMA_TFLOPS
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -144,37 +242,22 @@ def roofline_from_launches(model, x, steps):
             "launches_per_step": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 5),
             "flops_per_launch": g["flops"] / g["launches"],
             "all_conv_tflops": round(sum(v["flops"] for v in groups.values()) / (conv_ms * 1e-3) / 1e12, 2),
-            "forward_launch_ms_sum": round(float(tot.sum()), 4)}
+            "forward_launch_ms_sum": round(float(tot.sum()), 4),
+            "pointwise_convs": {"bound": "hbm", "launches": len(pw), "ms": round(pw_ms, 4),
+                                "achieved": round(pw_bytes / (pw_ms * 1e-3) / 1e9, 1) if pw_ms > 0 else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(pw_bytes / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pw_ms > 0 else None}}
     return roof, per_layer, groups
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--res", type=int, default=608)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
-    ap.add_argument("--conf", type=float, default=0.6)
-    ap.add_argument("--nms", type=float, default=0.5)
-    ap.add_argument("--precision", default=os.environ.get("RTOD_PRECISION", "f16s3"), choices=["fp32", "f16s3"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial-nms", action="store_true", help="run write_results on the forward's stream (no overlap with the next batch)")
-    ap.add_argument("--skew-frames", type=int, default=4, help="frames of the untimed forward that offsets the second stream (0: none)")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight: steps alternate over N plans (own activation arena) on N HIP streams, so one batch's "
-                         "partial rounds, prologues and epilogues overlap the other's kernels; 1 = strictly sequential forwards")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np  # noqa: F401
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
@@ -191,19 +274,20 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from realtimeobjectdetection_amd import synth
-    from realtimeobjectdetection_amd.util import write_results_async
+    from realtimeobjectdetection_amd.shard import FixedGather
+    from realtimeobjectdetection_amd.util import write_results, write_results_async
     B, R = args.batch, args.res
     model, ir, w, cfg_text = build_model(R, dev, B, args.precision)
     extra = [build_model(R, dev, B, args.precision)[0] for _ in range(max(0, args.inflight - 1))]
     models = [model] + extra
+    for m_ in models:
+        m_.overflow_check = "off"                       # the timed loops never read the range flag; checked once below
     fstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in extra]
     step_no = [0]
     # this rank's frame shard: frames [rank*B, (rank+1)*B) of the global synthetic stream
     x = torch.from_numpy(synth.synth_frames(B, R, seed=synth.FRAME_SEED + rank)).to(dev)
     CAP = 4096                                          # rows gathered per rank (fixed-capacity, no host sync)
-    if world > 1:
-        g_rows = torch.empty((world * CAP, 8), dtype=torch.float32, device=dev)
-        g_counts = torch.empty((world * 2,), dtype=torch.int32, device=dev)
+    gather = FixedGather(CAP, dev) if world > 1 else None
 
     # write_results (3 small latency-bound launches, ~0.1 ms) and the detection gather run on a second stream behind an
     # event, so that batch i's NMS overlaps batch i+1's first convolutions: the two batches are independent, every
@@ -212,10 +296,8 @@ def main():
 
     def post(y):
         rows, counts = write_results_async(y, 80, args.conf, args.nms, cap=CAP)
-        if world > 1:
-            rows[:, 0].add_(float(rank * B))        # global image index (detect.py:101-102)
-            dist.all_gather_into_tensor(g_rows, rows)
-            dist.all_gather_into_tensor(g_counts, counts[:2].contiguous())
+        if gather is not None:
+            gather.gather(rows, counts, rank * B)       # global image index (detect.py:101-102) + RCCL all-gather
         return rows, counts
 
     def step(nm):
@@ -231,23 +313,24 @@ def main():
                 y.record_stream(side)
         return y, rows, counts
 
-    def timed_run(nm):
-        """W untimed + K timed steps with `nm` batches in flight; returns (seconds, last step's tensors)."""
+    def step_dropin(_nm):
+        """The reference's calling sequence (detect.py:62-70): forward, then write_results with its host sync."""
+        with torch.no_grad():
+            y = model(x)
+            det = write_results(y, 80, args.conf, args.nms)
+        return y, det, None
+
+    def timed_run(fn, nm):
+        """W untimed + K timed steps; returns (seconds, last step's tensors)."""
         step_no[0] = 0
         for _ in range(args.warmup):
-            step(nm)
-        if nm == 2 and args.skew_frames > 0:
-            # untimed: one forward of half a batch on the second stream puts it about half a forward behind the first, so the
-            # two batches sit in different parts of the network (one in the HBM-bound early layers while the other is in the
-            # MFMA-bound deep ones) instead of running the same layer side by side: +1.2 % (1984 vs 1961 frames/s, same box)
-            with torch.no_grad(), torch.cuda.stream(fstreams[1]):
-                models[1](x[:min(args.skew_frames, B)].contiguous())
+            fn(nm)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step(nm)
+            out = fn(nm)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -262,14 +345,32 @@ def main():
         for m_ in models:
             m_(x)
     torch.cuda.synchronize()
-    dt, (y, rows, counts) = timed_run(len(models))
+    dt, (y, rows, counts) = timed_run(step, len(models))
+    n_det, n_cand = [int(v) for v in counts[:2].tolist()]
+    gathered = None
+    if gather is not None:
+        g = gather.compact()                            # content check of the last step's gather (host side, untimed)
+        gathered = 0 if isinstance(g, int) else int(g.size(0))
+    overflow = any(m_.overflowed() for m_ in models)    # split-f16 range guard over everything run so far
+
+    def rate(dt_):
+        return round(world * B * args.steps / dt_, 2), round(dt_ / args.steps * 1e3, 4)
+
     single = None
     if len(models) > 1:                                 # the strictly sequential figure beside the pipelined one
-        dt1, _ = timed_run(1)
-        single = {"value": round(world * B * args.steps / dt1, 2), "unit": "frames/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
-                  "note": "one batch in flight (forward i+1 starts after forward i; write_results still overlapped)"}
-    fps = world * B * args.steps / dt
-    n_det, n_cand = [int(v) for v in counts[:2].tolist()]
+        dt1, _ = timed_run(step, 1)
+        v, ms = rate(dt1)
+        single = {"value": v, "unit": "frames/s", "ms_per_step": ms,
+                  "note": "one batch in flight (forward i+1 starts after forward i); write_results_async on a second stream"}
+    model.overflow_check = "write_results"
+    dtd, (_, det, _) = timed_run(step_dropin, 1)
+    model.overflow_check = "off"
+    v, ms = rate(dtd)
+    dropin = {"value": v, "unit": "frames/s", "ms_per_step": ms,
+              "detections_last_step": 0 if isinstance(det, int) else int(det.size(0)),
+              "note": "reference calling sequence: y = model(x); write_results(y, 80, conf, nms) -> new [D,8] tensor; one plan, "
+                      "one stream, write_results' host sync (and the split-f16 range check) inside every step"}
+    fps, ms_step = rate(dt)
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -290,23 +391,30 @@ def main():
         cpu = cpu_baseline(cfg_text, w, R, B, args.conf, args.nms)
 
     if rank == 0:
+        sched = ("%d batches in flight, write_results_async on %s" % (len(models), "the forward's stream" if args.serial_nms else "a second stream")
+                 if len(models) > 1 else "one batch in flight, write_results_async")
         line = {
-            "metric": "frames/sec YOLOv3 %dx%d bs=%d (Darknet.forward + write_results)" % (R, R, B),
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": "frames/sec YOLOv3 %dx%d bs=%d (Darknet.forward + write_results; %s)" % (R, R, B, sched),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x2-split (3 MFMA products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "YOLOv3 cfg %dx%d batch=%d per GPU, %s MFMA conv + fused head + GPU NMS (BASELINE configs[%d])"
                                    % (R, R, B, "exact-fp32" if args.precision == "fp32" else "split-f16", 2 if R == 608 else 1),
                        "precision": args.precision,
                        "frames_per_step": world * B, "parallelism": "frame-shard x%d" % world,
-                       "in_flight_batches": len(models), "write_results_stream": "same" if args.serial_nms else "second stream",
+                       "in_flight_batches": len(models), "write_results": "async (device-side counts, capacity %d rows)" % CAP,
+                       "write_results_stream": "same" if args.serial_nms else "second stream",
                        "conf": args.conf, "nms": args.nms, "detections_last_step": n_det, "candidates_last_step": n_cand,
+                       "f16_range_overflow": bool(overflow),
                        "conv_gflop_per_frame": round(ir.conv_flops / 1e9, 3),
                        "whole_path_tflops": round(fps * ir.conv_flops / 1e12, 2),
                        "whole_path_frac_fp32_mfma_peak": round(fps * ir.conv_flops / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)},
         }
+        if gathered is not None:
+            line["config"]["gathered_detections_last_step"] = gathered
         if single is not None:
             line["single_stream"] = single
+        line["dropin_api"] = dropin
         if roof is not None:
             line["roofline"] = roof
         if cpu is not None:
@@ -314,6 +422,15 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))                     # no GPU call has been made in this process
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        args.gpus = int(os.environ["WORLD_SIZE"])
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@
  *  - every function returns 0 on success or a negative rtod_status; it never throws and never
  *    synchronises the device unless its comment says so;  rtod_last_error() returns the message
  *    of the calling thread's last failure;
+ *  - the library reads no environment variable: every behaviour switch is explicit per-plan state
+ *    (rtod_plan_set_precision, rtod_plan_set_option);
  *  - "dev" pointers are device (HBM) addresses owned by the caller (torch.Tensor.data_ptr());
  *    kernels are enqueued on the caller-supplied hipStream_t (void*; 0 = default stream);
  *  - a plan is not thread-safe; distinct plans are independent;
@@ -91,6 +93,20 @@ int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len);
  *      HBM as f16 hi/lo planes (x8 pre-scaled): needs |activation| < 8188, every conv after the
  *      stem with Cin % 32 == 0, no maxpool / stand-alone shortcut; otherwise RTOD_E_CFG. */
 int rtod_plan_set_precision(rtod_plan* plan, int mode);
+/* Plan options (call before rtod_plan_load_weights; re-plans buffers and launches).  All default to 1 / -1:
+ *   "fuse_pointwise"    1x1 conv in the previous conv's epilogue where one workgroup holds all its input channels
+ *   "fuse_shortcut"     shortcut (src/darknet.py:263-268) in the producing conv's epilogue; 0: stand-alone add kernel
+ *   "fuse_decode"       predict_transform (src/util.py:175-239) in the head conv's epilogue; 0: stand-alone decode kernel
+ *   "zero_copy_concat"  route producers (src/darknet.py:270-290) write into the concat buffer; 0: copy kernels
+ *   "stem_kernel"       dedicated NCHW-reading kernel for layer 0; 0: input pack + generic conv
+ *   "band_kernel"       LDS-band kernel for 3x3 stride-1 layers; 0: generic implicit GEMM
+ *   "force_f16s3_variant" / "force_f32_variant"   >= 0: one tile variant for every conv (tests, A/B runs)
+ * Options that leave a cfg inexpressible in the split-f16 format return RTOD_E_CFG when precision is 1. */
+int rtod_plan_set_option(rtod_plan* plan, const char* name, int value);
+/* Split-f16 plans store activations as f16 hi/lo planes of 8*x: |activation| must stay below 8188.  Producers
+ * saturate at that range (never inf / NaN) and OR 1 into *flag_dev (caller-owned device int32, zero it yourself)
+ * whenever a value saturated: read it at any synchronisation point.  NULL disables the report. */
+int rtod_plan_set_overflow_flag(rtod_plan* plan, int32_t* flag_dev);
 
 /* replaces Darknet.load_weights                              src/darknet.py:316-410
  * `w` is the float payload of a Darknet .weights file (after the 5xint32 header), host memory:
@@ -101,8 +117,15 @@ int rtod_plan_load_weights(rtod_plan* plan, const float* w, size_t n_floats);
 
 /* replaces Darknet.forward                                   src/darknet.py:199-303
  * x_dev: [batch,3,H,W] NCHW float32; out_dev: [batch,N,5+C] (new contiguous tensor in the
- * reference; here caller-allocated).  batch <= max_batch.  Enqueues only. */
+ * reference; here caller-allocated).  batch <= max_batch.  Enqueues only: no measurement, no host
+ * synchronisation, no allocation -> legal under hipStreamBeginCapture (a captured forward replays as a hipGraph). */
 int rtod_forward(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream);
+/* One forward that also measures, per distinct split-f16 conv shape, every tile variant on the layer's real input
+ * (HIP events on `stream`) and remembers the fastest for this batch size; later rtod_forward calls of that batch
+ * size use the table (untuned batch sizes use closed-form heuristics).  out_dev receives a valid forward result.
+ * Synchronises `stream` repeatedly; not capturable.  No-op (plain forward) for exact-fp32 plans.  Tile choice never
+ * changes results: every candidate of a layer sums its K products in the same order. */
+int rtod_plan_autotune(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream);
 /* Same, with a hipEvent pair around every launch (recorded on `stream`); synchronises and
  * writes the per-launch durations in ms to launch_ms[n_launches] (host).  For bench/roofline. */
 int rtod_forward_timed(rtod_plan* plan, const float* x_dev, int batch, float* out_dev,

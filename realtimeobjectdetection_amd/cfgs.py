@@ -3,9 +3,9 @@
 The reference reads ``cfg/yolov3.cfg`` and ``cfg/yolov3-tiny.cfg`` (reference:
 src/darknet.py:412-447 parses them, detect.py:185 picks the path from params.json).  Those
 files do not travel to the GPU box, so this module *generates* equivalent cfg text from a
-compact architecture description.  ``tests/test_cfg.py`` checks (in the build container,
-where /root/reference is mounted) that parsing the generated text yields layer blocks
-identical to parsing the reference's files.
+compact architecture description.  ``tests/test_oracle_golden.py::test_generated_cfg_equals_reference_cfg``
+checks (in the build container, where /root/reference is mounted) that parsing the generated text
+yields layer blocks identical to parsing the reference's files.
 
 Only keys that the hot path reads are emitted.
 """
@@ -90,7 +90,66 @@ def yolov3_tiny_cfg(height=416, width=416, classes=80) -> str:
     return "\n".join(L) + "\n"
 
 
+def mini_cfg(height=64, width=64, classes=80) -> str:
+    """Small residual network in the Darknet cfg grammar for tests: 24 layer blocks, every conv after the stem has
+    Cin % 32 == 0 (expressible in the split-f16 format), heads at stride 32 and 16.  At 64x64 the first head is a 2x2
+    grid: fewer cells than the decode epilogue's row step, ragged M tails on every tile shape."""
+    nout = 3 * (5 + classes)
+    L = _net(height, width)
+    L += _conv(32, 3, 1) + _conv(64, 3, 2)
+    L += _conv(32, 1, 1) + _conv(64, 3, 1) + _shortcut(-3)
+    L += _conv(128, 3, 2)
+    L += _conv(64, 1, 1) + _conv(128, 3, 1) + _shortcut(-3)
+    L += _conv(256, 3, 2) + _conv(512, 3, 2) + _conv(1024, 3, 2)
+    L += _conv(512, 1, 1) + _conv(1024, 3, 1)
+    L += _conv(nout, 1, 1, bn=False, act="linear") + _yolo((6, 7, 8), _ANCHORS_V3, 9, classes)
+    L += _route(-4) + _conv(256, 1, 1) + _upsample() + _route(-1, 10)
+    L += _conv(256, 1, 1) + _conv(512, 3, 1)
+    L += _conv(nout, 1, 1, bn=False, act="linear") + _yolo((3, 4, 5), _ANCHORS_V3, 9, classes)
+    return "\n".join(L) + "\n"
+
+
+def mini_fallback_cfg(height=64, width=64, classes=3) -> str:
+    """Legal cfg whose graph defeats every fusion of the planner, so the stand-alone kernels run (exact-fp32 plans):
+    a shortcut whose producer is an upsample (add kernel), a second concat of an already-placed layer (copy kernel),
+    a head conv that a later route also reads (stand-alone predict_transform), a max-pool of each kind."""
+    nout = 3 * (5 + classes)
+    L = _net(height, width)
+    L += _conv(32, 3, 1) + _conv(64, 3, 2)            # 0, 1: 64 @ 32x32
+    L += _conv(64, 3, 2)                               # 2: 64 @ 16x16
+    L += _conv(128, 3, 2) + _conv(64, 1, 1)            # 3, 4: 64 @ 8x8
+    L += _upsample()                                   # 5: 64 @ 16x16
+    L += _shortcut(-4)                                 # 6: upsample + layer 2 -> stand-alone add
+    L += _route(6, 2)                                  # 7: 128 @ 16x16, zero-copy
+    L += _conv(64, 1, 1)                               # 8
+    L += _route(8, 2)                                  # 9: layer 2 already lives in route 7's buffer -> copy kernel
+    L += _maxpool(2, 2) + _maxpool(2, 1)               # 10, 11: 128 @ 8x8
+    L += _conv(nout, 1, 1, bn=False, act="linear")     # 12: head conv, also read by route 14
+    L += _yolo((6, 7, 8), _ANCHORS_V3, 9, classes)     # 13: stand-alone decode (8x8 grid, stride 8)
+    L += _route(-2)                                    # 14: the raw head conv output again
+    L += _conv(32, 3, 2)                               # 15: 32 @ 4x4
+    L += _conv(nout, 1, 1, bn=False, act="linear") + _yolo((3, 4, 5), _ANCHORS_V3, 9, classes)   # 16, 17: fused decode, 4x4 grid
+    return "\n".join(L) + "\n"
+
+
 def write_cfg(path, text):
     with open(path, "w") as f:
         f.write(text)
     return path
+
+
+SHIPPED = {"yolov3.cfg": yolov3_cfg, "yolov3-tiny.cfg": yolov3_tiny_cfg}
+
+
+def ensure_cfg_files(directory):
+    """Write ``yolov3.cfg`` / ``yolov3-tiny.cfg`` (the two networks the reference ships under cfg/) into ``directory``
+    when they are missing; ``__graft_entry__.build()`` does this for ``<repo>/cfg`` so ``params.json`` resolves."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    out = []
+    for name, gen in SHIPPED.items():
+        p = os.path.join(directory, name)
+        if not os.path.exists(p):
+            write_cfg(p, gen())
+        out.append(p)
+    return out

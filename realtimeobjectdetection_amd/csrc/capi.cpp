@@ -117,6 +117,19 @@ int rtod_plan_set_precision(rtod_plan* plan, int mode) {
     return RTOD_OK;
 }
 
+int rtod_plan_set_option(rtod_plan* plan, const char* name, int value) {
+    RTOD_GUARD_BEGIN
+    if (!plan) { set_error("set_option: null plan"); return RTOD_E_ARG; }
+    return plan->p.set_option(name, value);
+    RTOD_GUARD_END
+}
+
+int rtod_plan_set_overflow_flag(rtod_plan* plan, int32_t* flag_dev) {
+    if (!plan) { set_error("set_overflow_flag: null plan"); return RTOD_E_ARG; }
+    plan->p.overflow_flag = flag_dev;
+    return RTOD_OK;
+}
+
 int rtod_plan_load_weights(rtod_plan* plan, const float* w, size_t n_floats) {
     RTOD_GUARD_BEGIN
     if (!plan) { set_error("load_weights: null plan"); return RTOD_E_ARG; }
@@ -128,6 +141,13 @@ int rtod_forward(rtod_plan* plan, const float* x_dev, int batch, float* out_dev,
     RTOD_GUARD_BEGIN
     if (!plan) { set_error("forward: null plan"); return RTOD_E_ARG; }
     return plan->p.forward(x_dev, batch, out_dev, (hipStream_t)stream, nullptr);
+    RTOD_GUARD_END
+}
+
+int rtod_plan_autotune(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream) {
+    RTOD_GUARD_BEGIN
+    if (!plan) { set_error("autotune: null plan"); return RTOD_E_ARG; }
+    return plan->p.forward(x_dev, batch, out_dev, (hipStream_t)stream, nullptr, true);
     RTOD_GUARD_END
 }
 

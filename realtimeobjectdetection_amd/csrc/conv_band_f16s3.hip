@@ -31,6 +31,7 @@
 //
 // Limits: stride 1, pad 1, 3x3, Cin % 32 == 0, W <= 94.
 #include "conv_f16s3_common.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -332,7 +333,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __syncthreads();
     RTOD_STAMP(6)                                              // 6: drain
 
+#ifdef RTOD_STAMPS
     if (a.dbg & 4) return;
+#endif
     conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
@@ -359,16 +362,16 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
     const int lds = main_bytes > BAND_EPI_BYTES ? main_bytes : BAND_EPI_BYTES;
     auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, KG>;
     auto k_plain = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, KG>;
-    static unsigned long long attr_done = 0;                   // per instantiation and device; > 64 KiB of dynamic LDS needs the opt-in
+    static std::atomic<unsigned long long> attr_done{0};       // per instantiation, one bit per device; > 64 KiB of dynamic LDS needs the opt-in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_band_f16s3 hipGetDevice");
-    if (!((attr_done >> (dev & 63)) & 1ull)) {
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {       // idempotent: a second thread may repeat the calls
         const int cap = KG * (4 * BN * 64 + 2 * (band_rows(BM, BAND_MAX_W) + 1) * 64);
         const int mx = cap > BAND_EPI_BYTES ? cap : BAND_EPI_BYTES;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return hip_fail(hipGetLastError(), "conv_band_f16s3 LDS attribute");
-        attr_done |= 1ull << (dev & 63);
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
@@ -437,10 +440,12 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (a.in_ldc % 8 || a.in_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin) { set_error("launch_conv_band: bad view / K"); return RTOD_E_ARG; }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_band: buffer extents"); return RTOD_E_ARG; }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_band: input view exceeds its buffer"); return RTOD_E_ARG; }
-    static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;
+#ifdef RTOD_STAMPS
+    static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;   // diagnostic build only
     if (dbg_zero & 1) a.in_bytes = 1;
     if (dbg_zero & 2) a.w_bytes = 1;
     a.dbg = dbg_zero;
+#endif
     switch (mode) {
 #define RTOD_X_CASE(m, bm, bn, nwm, nwn, minw, kg, sfx) case m: return launch_band<bm, bn, nwm, nwn, minw, kg>(a, s);
         RTOD_BAND_TILES(RTOD_X_CASE)

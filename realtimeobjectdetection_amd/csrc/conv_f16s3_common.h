@@ -43,10 +43,12 @@ __device__ __forceinline__ u32x4 asm_buffer_load_b128(const __amdgpu_buffer_rsrc
 // 16-byte activation store, sc1 (write-through): a layer's output is read by the NEXT kernel, on all XCDs, so it has
 // to reach memory anyway; written back line by line while the kernel runs it leaves the kernel-end release little
 // dirty L2 to drain (measured +1.2 % frames/s over plain write-back stores; non-temporal stores: -2.7 %).
-// `plain` (RTOD_DBG_ZERO bit 8) keeps the write-back store for that comparison.
+// `plain` (diagnostic build, RTOD_DBG_ZERO bit 8) keeps the write-back store for that comparison.
 __device__ __forceinline__ void store_act16(_Float16* p, const f16x8& v, bool plain) {
-    if (plain) *reinterpret_cast<f16x8*>(p) = v;
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#ifdef RTOD_STAMPS
+    if (plain) { *reinterpret_cast<f16x8*>(p) = v; return; }
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
 constexpr int epi_row_group(int bm, int wm, int rg_max) {
@@ -81,7 +83,12 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
     static_assert(RG >= WM && BM % RG == 0, "epilogue row group");
     float* T = reinterpret_cast<float*>(smem);
     const int hw = a.Ho * a.Wo;
+#ifdef RTOD_STAMPS
     const bool st_plain = (a.dbg & 8) != 0;
+#else
+    constexpr bool st_plain = false;
+#endif
+    float amax = 0.f;                                                    // overflow sentinel of the split-format stores
     // fused pointwise conv: a wave owns one 16-column group of the second GEMM; its B fragments (the whole K of the
     // 1x1 conv, <= 4 k32 steps) are fetched once here, their latency hidden behind the transpose and the first store pass
     constexpr int PWK = PW_MAX_K / 32;
@@ -194,7 +201,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
                     *op = o;
                     op += row_step; cell += RSTEP; gx += RSTEP;
                     while (gx >= a.dec.G) { gx -= a.dec.G; ++gy; }
-                    if (cell >= hw) { cell -= hw; gy -= a.dec.G; op += img_fix; }
+                    while (cell >= hw) { cell -= hw; gy -= a.dec.G; op += img_fix; }   // G*G < RSTEP: a step may cross several images
                 }
             }
         } else {
@@ -221,11 +228,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
                 }
                 f16x8 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const _Float16 h = (_Float16)v[e];
-                    ph[e] = h;
-                    pl[e] = (_Float16)(v[e] - (float)h);
-                }
+                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f16(v[e], h, l, amax); ph[e] = h; pl[e] = l; }
                 _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
                 store_act16(q, ph, st_plain);
                 store_act16(q + a.out_ldc, pl, st_plain);
@@ -279,11 +282,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(T2 + r * T2S + c8 + 4);
                     f16x8 ph, pl;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = e < 4 ? v0[e] : v1[e - 4];
-                        const _Float16 h = (_Float16)v;
-                        ph[e] = h; pl[e] = (_Float16)(v - (float)h);
-                    }
+                    for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f16(e < 4 ? v0[e] : v1[e - 4], h, l, amax); ph[e] = h; pl[e] = l; }
                     _Float16* q = oh2 + (int64_t)m * 2 * a.pw_out_ldc + c8;
                     store_act16(q, ph, st_plain);
                     store_act16(q + a.pw_out_ldc, pl, st_plain);
@@ -292,6 +291,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
         }
         if (rg + RG < BM) __syncthreads();
     }
+    if constexpr (EPI != EPI_DECODE) split_overflow_report(a.ovf, amax);
 }
 
 }  // namespace rtod

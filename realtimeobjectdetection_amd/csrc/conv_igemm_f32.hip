@@ -157,6 +157,7 @@ void conv_igemm_f32_kernel(const ConvArgs a, const int grid_m, const int grid_n)
 
     // epilogue: D col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
     const int hw = a.Ho * a.Wo;
+    float amax = 0.f;                                  // overflow sentinel when writing the split format
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = bn * BN + wn * WN + j * 32 + lr;
@@ -178,17 +179,18 @@ void conv_igemm_f32_kernel(const ConvArgs a, const int grid_m, const int grid_n)
                     a.out[(int64_t)b * a.dec.img_stride + a.dec.head_off + (int64_t)cell * a.Cout + n] = v;
                 } else if (a.out_split) {
                     // split format for a following conv_igemm_f16s3 layer: 8*v as f16 hi + f16 lo planes
-                    const float v8 = v * SPLIT_SCALE;
-                    const _Float16 h = (_Float16)v8;
+                    _Float16 h, l;
+                    split_f16(v * SPLIT_SCALE, h, l, amax);
                     _Float16* oh = reinterpret_cast<_Float16*>(a.out) + (int64_t)m * 2 * a.out_ldc + a.out_coff + n;
                     oh[0] = h;
-                    oh[a.out_ldc] = (_Float16)(v8 - (float)h);
+                    oh[a.out_ldc] = l;
                 } else {
                     a.out[(int64_t)m * a.out_ldc + a.out_coff + n] = v;
                 }
             }
         }
     }
+    if (a.out_split) split_overflow_report(a.ovf, amax);
 }
 
 static const ConvVariantInfo kVariants[CV_COUNT] = {

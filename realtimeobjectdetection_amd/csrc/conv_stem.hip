@@ -138,6 +138,7 @@ struct StemSplitArgs {
     _Float16* out; int64_t out_ldc; int out_coff;
     int B, H, W, Ho, Wo, stride, Cout, leaky;
     unsigned x_bytes;
+    int32_t* ovf;
 };
 
 __global__ __launch_bounds__(256)
@@ -152,6 +153,7 @@ void conv_stem_split_kernel(const StemSplitArgs a) {
     float* Tw = T[wave];
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     int koff[8], need[8];
+    float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = lh * 8 + e;                                  // 0..31, k = (ky*3+kx)*3 + c
@@ -243,9 +245,9 @@ void conv_stem_split_kernel(const StemSplitArgs a) {
                 f16x8s pk;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = (e < 4 ? v0[e] : v1[e - 4]) * SPLIT_SCALE;
-                    const _Float16 h = (_Float16)v;
-                    pk[e] = j < 4 ? h : (_Float16)(v - (float)h);
+                    _Float16 h, l;
+                    split_f16((e < 4 ? v0[e] : v1[e - 4]) * SPLIT_SCALE, h, l, amax);
+                    pk[e] = j < 4 ? h : l;
                 }
                 if (mo < M) {
                     _Float16* o = a.out + (int64_t)mo * 2 * a.out_ldc + a.out_coff + ct * 32 + c8 + (j < 4 ? 0 : a.out_ldc);
@@ -260,15 +262,17 @@ void conv_stem_split_kernel(const StemSplitArgs a) {
                 for (int e = 0; e < 8; ++e) av[i][e] = an[i][e];
         }
     }
+    split_overflow_report(a.ovf, amax);
 }
 
 int launch_conv_stem_split(const float* x, const _Float16* wh, const _Float16* wl, const float* inv_scale, const float* bias,
-                           const View& out, int B, int H, int W, int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s) {
+                           const View& out, int B, int H, int W, int Ho, int Wo, int stride, int Cout, int leaky, int32_t* ovf, hipStream_t s) {
     if (!x || !wh || !wl || !inv_scale || !bias || !out.base) { set_error("conv_stem_split: null pointer"); return RTOD_E_ARG; }
     if (Cout % 32 || Cout < 32 || out.C != Cout || out.H != Ho || out.W != Wo || out.ldc % 8 || out.coff % 8 || !out.split) { set_error("conv_stem_split: bad output view"); return RTOD_E_ARG; }
     if ((int64_t)B * Ho * Wo >= (1ll << 31) || (int64_t)B * 3 * H * W * 4 >= (1ll << 31)) { set_error("conv_stem_split: input exceeds 2 GiB / int32 pixels"); return RTOD_E_ARG; }
     StemSplitArgs a;
     a.x_bytes = (unsigned)((int64_t)B * 3 * H * W * 4);
+    a.ovf = ovf;
     a.x = x; a.wh = wh; a.wl = wl; a.inv_scale = inv_scale; a.bias = bias;
     a.out = reinterpret_cast<_Float16*>(out.base); a.out_ldc = out.ldc; a.out_coff = out.coff;
     a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.Cout = Cout; a.leaky = leaky;

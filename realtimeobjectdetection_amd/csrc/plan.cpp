@@ -270,6 +270,41 @@ static int resolve_alias(const std::vector<Layer>& layers, int i) {
     return i;
 }
 
+void Plan::reset_planning() {
+    for (auto& L : layers) { L.fused_into = -1; L.fused_away = false; L.buf = -1; L.coff = 0; L.alias_of = -1; }
+    bufs.clear(); launches.clear(); convs.clear(); input_buf = -1;
+    tuned.clear(); tune_cache.clear(); tuning.clear();
+}
+
+int Plan::set_option(const char* name, int value) {
+    if (!name) { set_error("set_option: null name"); return RTOD_E_ARG; }
+    if (d_weights) { set_error("set_option: must be called before rtod_plan_load_weights"); return RTOD_E_STATE; }
+    const std::string k(name);
+    bool* flag = nullptr; int* num = nullptr;
+    if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
+    else if (k == "stem_kernel") flag = &opt_stem_kernel;
+    else if (k == "band_kernel") flag = &opt_band_kernel;
+    else if (k == "fuse_shortcut") flag = &opt_fuse_shortcut;
+    else if (k == "fuse_decode") flag = &opt_fuse_decode;
+    else if (k == "zero_copy_concat") flag = &opt_zero_copy_concat;
+    else if (k == "force_f16s3_variant") num = &opt_force_f16s3_variant;
+    else if (k == "force_f32_variant") num = &opt_force_f32_variant;
+    else { set_error("set_option: unknown option '%s'", name); return RTOD_E_ARG; }
+    const bool old_flag = flag ? *flag : false; const int old_num = num ? *num : 0;
+    if (flag) *flag = value != 0; else *num = value;
+    reset_planning();
+    int rc = plan_buffers();
+    if (!rc && precision == 1) rc = check_split_supported();
+    if (rc) {                                                  // refuse: the plan stays as it was (the error message is kept)
+        const std::string msg = last_error_string();
+        if (flag) *flag = old_flag; else *num = old_num;
+        reset_planning();
+        (void)plan_buffers();
+        set_error("%s", msg.c_str());
+    }
+    return rc;
+}
+
 int Plan::plan_buffers() {
     const int n = (int)layers.size();
     // consumers of every layer's output
@@ -292,8 +327,8 @@ int Plan::plan_buffers() {
         if (i == 0) continue;
         Layer& P = layers[i - 1];
         if (P.type != LT_CONV || P.fused_into >= 0 || cons[i - 1].size() != 1) continue;
-        if (L.type == LT_SHORTCUT && L.srcs[1] != i - 1) { P.fused_into = i; L.fused_away = true; }
-        else if (L.type == LT_YOLO && cons[i].empty()) { P.fused_into = i; L.fused_away = true; }
+        if (L.type == LT_SHORTCUT && L.srcs[1] != i - 1 && opt_fuse_shortcut) { P.fused_into = i; L.fused_away = true; }
+        else if (L.type == LT_YOLO && cons[i].empty() && opt_fuse_decode) { P.fused_into = i; L.fused_away = true; }
     }
     // materialised producers: every non-alias layer except convs fused into the next layer and
     // fused yolo layers (their "output" is the final tensor)
@@ -317,7 +352,7 @@ int Plan::plan_buffers() {
         for (int s : L.srcs) {
             const int p = resolve_alias(layers, s);
             const Layer& PL = layers[p];
-            const bool can = materialised(PL) && PL.type != LT_ROUTE && placed_buf[p] < 0 && off % 4 == 0 && PL.cout % 4 == 0 &&
+            const bool can = opt_zero_copy_concat && materialised(PL) && PL.type != LT_ROUTE && placed_buf[p] < 0 && off % 4 == 0 && PL.cout % 4 == 0 &&
                              std::count(L.srcs.begin(), L.srcs.end(), s) == 1;
             if (can) { placed_buf[p] = bid; placed_off[p] = off; }
             else route_copy[L.index].push_back({s, off});
@@ -346,7 +381,7 @@ int Plan::plan_buffers() {
     if (layers[0].type != LT_CONV) { set_error("cfg: first layer must be convolutional"); return RTOD_E_CFG; }
     // dedicated stem kernel (reads NCHW directly) when layer 0 is a plain 3x3 / pad 1 conv with 32 or 64 filters
     const bool use_stem = layers[0].size == 3 && layers[0].pad == 1 && layers[0].cin == 3 && layers[0].cout % 32 == 0 &&
-                          layers[0].cout <= 64 && layers[0].fused_into < 0 && !getenv("RTOD_NO_STEM");
+                          layers[0].cout <= 64 && layers[0].fused_into < 0 && opt_stem_kernel;
     if (!use_stem) { Launch l; l.kind = LK_PACK; l.layer = 0; launches.push_back(l); }
     for (auto& L : layers) {
         const int i = L.index;
@@ -483,7 +518,7 @@ void Plan::layout_weights() {
             pc.wl_off = packed_floats; packed_floats += panel / 2;      // f16 lo plane
             pc.s_off = packed_floats; packed_floats += pc.Npad;
             pc.band = conv_band_supported(L.size, L.stride, L.pad, L.cin, L.win) && L.hout == L.hin &&
-                      !(L.fused_into >= 0 && layers[L.fused_into].type == LT_YOLO) && !getenv("RTOD_NO_BAND");
+                      !(L.fused_into >= 0 && layers[L.fused_into].type == LT_YOLO) && opt_band_kernel;
         } else {
             pc.w_off = packed_floats; packed_floats += panel;
         }
@@ -677,8 +712,7 @@ int Plan::load_weights(const float* w, size_t n) {
 
 // ------------------------------------------------------------------------------------- forward
 int Plan::choose_variant(const Layer& L, int batch) const {
-    const char* force = getenv("RTOD_CONV_VARIANT");
-    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < CV_COUNT) return v; }
+    if (opt_force_f32_variant >= 0 && opt_force_f32_variant < CV_COUNT) return opt_force_f32_variant;
     if (L.cout <= 32) return CV_128x32;
     if (L.cout <= 64) return CV_128x64;
     const int64_t M = (int64_t)batch * L.hout * L.wout;
@@ -710,6 +744,7 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
     }
     a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
     a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
+    a.ovf = overflow_flag;
     if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
     if (l.out_layer == -2) { a.out = out; a.dec = l.dec; a.dec.train = train_decode; }
     else {
@@ -819,10 +854,9 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
 }
 
 int Plan::variant_for(const Launch& l, int batch) const {
-    const char* force = getenv("RTOD_F16S3_VARIANT");
     const bool band = convs[l.conv_slot].band;
-    if (force && *force) {                                   // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
-        const int v = atoi(force);
+    if (opt_force_f16s3_variant >= 0) {                      // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
+        const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
         const int g = choose_variant_f16s3(layers[l.layer], batch);
@@ -839,11 +873,10 @@ int Plan::variant_for(const Launch& l, int batch) const {
     return v;
 }
 
-bool Plan::pw_active() const { return precision == 1 && !getenv("RTOD_NO_PW"); }
+bool Plan::pw_active() const { return precision == 1 && opt_fuse_pointwise; }
 
 int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
-    const char* force = getenv("RTOD_F16S3_VARIANT");
-    if (force && *force) { const int v = atoi(force); if (v >= 0 && v < HV_COUNT) return v; }
+    if (opt_force_f16s3_variant >= 0 && opt_force_f16s3_variant < HV_COUNT) return opt_force_f16s3_variant;
     if (L.cout <= 64) return HV_128x64;
     const int64_t M = (int64_t)batch * L.hout * L.wout;
     const int64_t gn = (L.cout + 127) / 128;
@@ -852,13 +885,13 @@ int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
     return HV_64x64;
 }
 
-int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms) {
+int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms, bool tune) {
     if (!weights_loaded) { set_error("forward: load_weights has not been called"); return RTOD_E_STATE; }
     if (!x || !out) { set_error("forward: null pointer"); return RTOD_E_ARG; }
     if (batch < 1 || batch > max_batch) { set_error("forward: batch %d outside 1..%d", batch, max_batch); return RTOD_E_ARG; }
     RTOD_HIP(hipSetDevice(device));
-    const char* forced = getenv("RTOD_F16S3_VARIANT");
-    const bool tune_now = precision == 1 && !tuned.count(batch) && !getenv("RTOD_NO_AUTOTUNE") && !(forced && *forced);   // first forward of a batch size
+    // rtod_plan_autotune only: rtod_forward never measures, never synchronises (safe under stream capture)
+    const bool tune_now = tune && precision == 1 && opt_force_f16s3_variant < 0;
     if (tune_now) { tuning.assign(launches.size(), -1); tune_cache.clear(); }
     const size_t nl = launches.size();
     if (launch_ms && events.size() < 2 * nl) {
@@ -895,7 +928,7 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 if (pc.split)
                     rc = launch_conv_stem_split(x, reinterpret_cast<const _Float16*>(d_weights + pc.w_off), reinterpret_cast<const _Float16*>(d_weights + pc.wl_off),
                                                 d_weights + pc.s_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
-                                                L.stride, L.cout, L.leaky ? 1 : 0, s);
+                                                L.stride, L.cout, L.leaky ? 1 : 0, overflow_flag, s);
                 else
                     rc = launch_conv_stem(x, d_weights + pc.w_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
                                           L.stride, L.cout, L.leaky ? 1 : 0, s);
@@ -923,7 +956,6 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
         if (launch_ms) RTOD_HIP(hipEventRecord(events[2 * li + 1], s));
     }
     if (tune_now) tuned[batch] = tuning;
-    else if (precision == 1 && !tuned.count(batch)) tuned[batch] = std::vector<int>(launches.size(), -1);
     if (launch_ms) {
         RTOD_HIP(hipEventSynchronize(events[2 * nl - 1]));
         for (size_t li = 0; li < nl; ++li) RTOD_HIP(hipEventElapsedTime(&launch_ms[li], events[2 * li], events[2 * li + 1]));

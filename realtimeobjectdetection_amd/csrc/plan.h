@@ -81,6 +81,17 @@ struct Plan {
     int train_decode = 0;
     int precision = 0;         // 0 = exact fp32 MFMA, 1 = f16 hi/lo split (3 products)
     bool keep_all = false;     // debug: no arena reuse, every layer output stays readable after forward
+    // plan options (rtod_plan_set_option, before rtod_plan_load_weights).  Explicit per-plan state: the library reads no
+    // environment variable.
+    bool opt_fuse_pointwise = true;   // run a 1x1 conv in the previous conv's epilogue where the plan allows it
+    bool opt_stem_kernel = true;      // dedicated NCHW-reading kernel for layer 0 (else pack + generic conv)
+    bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
+    bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
+    bool opt_fuse_decode = true;      // head decode in the head conv's epilogue (else stand-alone decode kernel)
+    bool opt_zero_copy_concat = true; // route producers write straight into the concat buffer (else copy kernels)
+    int opt_force_f16s3_variant = -1; // >= 0: tile variant for every split-f16 conv (>= BAND_VARIANT_BASE: band layers)
+    int opt_force_f32_variant = -1;   // >= 0: tile variant for every exact-fp32 conv
+    int32_t* overflow_flag = nullptr; // caller-owned device word: split-f16 producers OR 1 into it when a value saturates
     std::vector<hipEvent_t> events;
 
     ~Plan();
@@ -92,7 +103,9 @@ struct Plan {
     bool uses_split(const Layer& L, int cin_p) const;
     int check_split_supported() const;
     int load_weights(const float* w, size_t n);
-    int forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms);
+    int forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms, bool tune = false);
+    int set_option(const char* name, int value);
+    void reset_planning();
     View view_of(int layer) const;            // resolves aliases; base == nullptr if not materialised
     int choose_variant(const Layer& L, int batch) const;
     int choose_variant_f16s3(const Layer& L, int batch) const;

@@ -61,7 +61,8 @@ struct ConvArgs {
     const _Float16* w_lo = nullptr;
     const float* inv_scale = nullptr;           // [Npad]: 1 / (2^e_n * SPLIT_SCALE)
     unsigned in_bytes = 0, w_bytes = 0;         // extents of the input buffer / one weight plane (buffer-load range check)
-    int dbg = 0;                                // timing experiments only (RTOD_DBG_ZERO)
+    int dbg = 0;                                // timing experiments, diagnostic build only (-DRTOD_STAMPS reads RTOD_DBG_ZERO); the product library never sets or reads it
+    int32_t* ovf = nullptr;                     // split-format producers: device word that gets 1 OR-ed in when an activation saturates the f16 range
     int xcd_by_n = 0;                           // split kernels: workgroup -> XCD by output-channel tile instead of by pixel tile (see launch_band)
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
     // split path, fused trailing 1x1 conv ("pointwise", conv_f16s3_common.h): the workgroup holds every channel of its
@@ -77,6 +78,21 @@ struct ConvArgs {
 // Split activation format: value * SPLIT_SCALE stored as f16 hi + f16 lo planes per pixel.
 constexpr float SPLIT_SCALE = 8.0f;
 constexpr float ACT_SCALE_F16S3 = SPLIT_SCALE;
+constexpr float F16_MAX = 65504.0f;
+
+#ifdef __HIPCC__
+// v (already x SPLIT_SCALE) -> hi + lo.  Saturates at the f16 range instead of producing inf (inf + -inf = NaN in the
+// next layer); `amax` tracks max|v| for the overflow sentinel (split_overflow_report).
+__device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l, float& amax) {
+    amax = fmaxf(amax, fabsf(v));
+    const float vc = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+    h = (_Float16)vc;
+    l = (_Float16)(vc - (float)h);
+}
+__device__ __forceinline__ void split_overflow_report(int32_t* flag, float amax) {
+    if (flag && !(amax <= F16_MAX)) atomicOr(flag, 1);        // also true for NaN
+}
+#endif
 
 enum ConvVariant { CV_128x128 = 0, CV_128x64 = 1, CV_64x64 = 2, CV_128x32 = 3, CV_COUNT };
 struct ConvVariantInfo { int bm, bn; const char* name; };
@@ -106,7 +122,7 @@ constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the ban
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
 int launch_conv_stem_split(const float* x_nchw, const _Float16* wh, const _Float16* wl, const float* inv_scale, const float* bias,
-                           const View& out, int B, int H, int W, int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);
+                           const View& out, int B, int H, int W, int Ho, int Wo, int stride, int Cout, int leaky, int32_t* ovf, hipStream_t s);
 int launch_prep_image(const unsigned char* img, int h, int w, int bgr, int inp_dim, float* out, hipStream_t s);
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);

@@ -21,6 +21,8 @@ enabled explicitly.
 import ctypes as C
 import json
 import os
+import warnings
+import weakref
 from contextlib import contextmanager
 
 import numpy as np
@@ -29,6 +31,18 @@ import torch.nn as nn
 
 from . import _ffi
 from .cfg import parse_cfg, build_ir
+
+
+_pending_overflow = {}      # output data_ptr -> weakref(model): util.write_results reads the model's overflow flag at its host sync
+
+
+def check_overflow_for(prediction):
+    """Called by util.write_results after its host synchronisation: raises if the forward that produced this
+    prediction tensor saturated a split-f16 activation."""
+    ref = _pending_overflow.pop(prediction.data_ptr(), None)
+    model = ref() if ref is not None else None
+    if model is not None:
+        model.check_overflow()
 
 
 class EmptyLayer(nn.Module):
@@ -81,6 +95,14 @@ class Darknet(nn.Module):
         self.bn_running_stats_in_train = False
         self.precision = os.environ.get("RTOD_PRECISION", "auto")   # "fp32" (exact MFMA) | "f16s3" (split f16, 3 products) | "auto"
         self.keep_all_layers = False      # debug: no activation-arena reuse (read_layer after forward)
+        self.autotune = True              # split-f16 plans: measure the tile variants once per batch size (rtod_plan_autotune)
+        self.options = {}                 # rtod_plan_set_option name -> int (fusion / kernel-selection switches, tests and A/B runs)
+        # split-f16 range guard (|activation| < 8188): producers saturate and raise a device flag.  "write_results": the flag
+        # is read at write_results' existing host sync; "forward": read (one host sync) after every forward, and with
+        # precision "auto" the plan falls back to the exact-fp32 kernels and re-runs; "off": never read.
+        self.overflow_check = "write_results"
+        self._ovf = None
+        self._tuned = set()
         self._cfg_text = _blocks_to_cfg_text(self.blocks)
         self._plan = None
         self._plan_key = None
@@ -218,15 +240,21 @@ class Darknet(nn.Module):
         inp_dim = int(self.net_info["height"])
         if self.precision not in ("fp32", "f16s3", "auto"):
             raise ValueError("Darknet.precision must be 'fp32', 'f16s3' or 'auto'")
-        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers), self.precision)
+        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers), self.precision, tuple(sorted(self.options.items())))
         if self._plan is None or self._plan_key != key:
             self._destroy_plan()
             h = C.c_void_p()
             txt = self._cfg_text.encode()
             _ffi.check(lib.rtod_plan_create(txt, len(txt), inp_dim, inp_dim, int(max_batch), device.index, C.byref(h)))
             self._plan, self._plan_key = h, key
+            self._tuned = set()
             if self.keep_all_layers:
                 _ffi.check(lib.rtod_plan_set_keep_all_layers(self._plan, 1))
+            for name, value in sorted(self.options.items()):
+                _ffi.check(lib.rtod_plan_set_option(self._plan, name.encode(), int(value)))
+            if self._ovf is None or self._ovf.device != device:
+                self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
+            _ffi.check(lib.rtod_plan_set_overflow_flag(self._plan, C.c_void_p(self._ovf.data_ptr())))
             # "auto": the split-f16 kernels when the cfg supports them (yolov3 does; cfgs with maxpool or
             # Cin % 32 != 0 such as yolov3-tiny do not), else the exact-fp32 MFMA kernels.  Both are HIP paths.
             if self.precision == "fp32":
@@ -298,7 +326,12 @@ class Darknet(nn.Module):
         with torch.cuda.device(x.device):
             _ffi.check(lib.rtod_plan_set_train_decode(self._plan, 1 if self.TRAIN else 0))
             if _launch_ms is None:
-                _ffi.check(lib.rtod_forward(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream))
+                if self.autotune and self.active_precision == "f16s3" and B not in self._tuned:
+                    # first forward of a batch size: measures the tile variants (synchronises); rtod_forward itself never does
+                    _ffi.check(lib.rtod_plan_autotune(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream))
+                    self._tuned.add(B)
+                else:
+                    _ffi.check(lib.rtod_forward(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream))
             else:
                 _ffi.check(lib.rtod_forward_timed(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream, _launch_ms))
         # attributes the reference sets as a side effect of forward (src/darknet.py:239-243, 260)
@@ -308,7 +341,35 @@ class Darknet(nn.Module):
                 anchors.extend(m[0].anchors)
                 self.num_classes = int(blk["classes"])
         self.anchors = anchors
+        if self.active_precision == "f16s3" and self.overflow_check != "off":
+            if self.overflow_check == "forward":
+                if self.overflowed():
+                    if self.precision != "auto":
+                        self.check_overflow()
+                    warnings.warn("Darknet: an activation left the split-f16 range (|x| >= 8188); precision 'auto' falls back to the "
+                                  "exact-fp32 MFMA kernels for this model", RuntimeWarning)
+                    self.precision = "fp32"
+                    return self.forward(x)
+            else:
+                _pending_overflow[out.data_ptr()] = weakref.ref(self)
+                if len(_pending_overflow) > 64:
+                    _pending_overflow.pop(next(iter(_pending_overflow)))
         return out
+
+    def overflowed(self) -> bool:
+        """True when a split-f16 producer saturated since the last call (one small host sync); clears the flag."""
+        if self._ovf is None:
+            return False
+        hit = bool(int(self._ovf.item()))
+        if hit:
+            self._ovf.zero_()
+        return hit
+
+    def check_overflow(self):
+        if self.overflowed():
+            raise FloatingPointError(
+                "Darknet (precision f16s3): an activation reached the split-f16 range limit (|x| >= 8188) and was saturated; "
+                "the results of that forward are not valid. Use precision='fp32' (exact MFMA kernels) for these weights.")
 
     def forward_timed(self, x):
         """Forward with a HIP-event pair around every launch; returns (out, ms per launch)."""

@@ -50,3 +50,42 @@ def gather_detections(local_rows, frame_offset: int, device=None, group=None):
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+class FixedGather:
+    """Fixed-capacity detection gather without a host synchronisation (what ``bench.py`` runs every step).
+
+    ``gather_detections`` sizes its second all-gather from the first one's counts: one host round trip per batch.  A
+    detector that keeps several batches in flight instead gathers a fixed ``cap`` rows per rank plus the counts and
+    compacts on the host only when it consumes the result.  Buffers are allocated once; ``gather`` enqueues two
+    ``all_gather_into_tensor`` calls (RCCL over xGMI with the nccl backend: ``cap*32`` bytes per rank, latency-bound) on
+    the current stream and returns device tensors; ``compact`` (host side, after a sync) yields exactly what
+    ``gather_detections`` returns: rows in single-process order (image-major) or the int 0.
+    """
+
+    def __init__(self, cap: int, device, group=None):
+        self.cap, self.group = int(cap), group
+        self.world = dist.get_world_size(group)
+        self.rows = torch.empty((self.world * self.cap, 8), dtype=torch.float32, device=device)
+        self.meta = torch.empty((self.world * 2,), dtype=torch.int32, device=device)
+
+    def gather(self, local_rows: torch.Tensor, local_counts: torch.Tensor, frame_offset: int):
+        """``local_rows`` ``[cap,8]`` and ``local_counts`` (``[0]`` = valid rows, ``[1]`` = candidates) as returned by
+        ``util.write_results_async(..., cap=cap)``.  The image column is shifted in place by this rank's first frame
+        (detect.py:101-102 does the same per batch)."""
+        assert local_rows.shape == (self.cap, 8)
+        local_rows[:, 0].add_(float(frame_offset))
+        dist.all_gather_into_tensor(self.rows, local_rows, group=self.group)
+        dist.all_gather_into_tensor(self.meta, local_counts[:2].contiguous(), group=self.group)
+        return self.rows, self.meta
+
+    def compact(self):
+        """Host side: ``[D,8]`` rows in rank (= image) order, an empty tensor when candidates existed but none survived,
+        or 0 when no rank had a candidate (the reference's conventions, src/util.py:343-346)."""
+        meta = self.meta.view(self.world, 2).tolist()
+        if any(int(d) > self.cap for d, _ in meta):
+            raise RuntimeError("FixedGather: a rank produced %d detections, capacity is %d" % (max(int(d) for d, _ in meta), self.cap))
+        if not any(int(c) for _, c in meta):
+            return 0
+        parts = [self.rows[r * self.cap: r * self.cap + int(meta[r][0])] for r in range(self.world)]
+        return torch.cat(parts, 0)

@@ -171,3 +171,29 @@ def synth_predictions(batch: int, n: int, classes: int, res: int, seed: int = PR
                 o[d] = v
                 u = np.append(u, v)
     return p
+
+
+def conv_weight_slices(ir: NetIR):
+    """``{layer index: (start, stop)}`` of each conv's OIHW weight block inside the ``.weights`` float stream."""
+    out, p = {}, 0
+    for L in ir.layers:
+        if L.type != "convolutional":
+            continue
+        p += (4 if L.bn else 1) * L.cout
+        n = L.cout * L.cin * L.size * L.size
+        out[L.index] = (p, p + n)
+        p += n
+    return out
+
+
+def scale_conv_weights(ir: NetIR, w: np.ndarray, factor: float, layers=None) -> np.ndarray:
+    """Copy of the stream with the weight blocks of ``layers`` (default: every linear head conv) multiplied by ``factor``:
+    drives head logits to |t| ~ factor * HEAD_LOGIT_STD, or an inner layer out of the split-f16 range."""
+    sl = conv_weight_slices(ir)
+    if layers is None:
+        layers = [L.index for L in ir.layers if L.type == "convolutional" and not L.bn]
+    out = w.copy()
+    for i in layers:
+        a, b = sl[i]
+        out[a:b] *= np.float32(factor)
+    return out

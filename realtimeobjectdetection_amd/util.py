@@ -184,6 +184,8 @@ def write_results(prediction, num_class, confidence=0.6, nms_conf=0.4):
     out, counts = write_results_async(prediction, num_class, confidence, nms_conf)
     c = counts[:2].tolist()                    # one host sync, like the reference's own .tolist()/nonzero
     D, cand = int(c[0]), int(c[1])
+    from .darknet import check_overflow_for
+    check_overflow_for(prediction)             # split-f16 range guard of the forward that produced `prediction`
     if D > out.size(0):                        # more detections than the default capacity: redo at full size
         out, counts = write_results_async(prediction, num_class, confidence, nms_conf, cap=B * n)
         D = int(counts[0].item())

@@ -118,3 +118,40 @@ def test_detector_driver_end_to_end(tmp_path):
             rows = np.array(saved[name], dtype=np.float32)
             assert rows.shape[1] == 8 and np.all(rows[:, 0] == idx)
             assert np.allclose(rows[:, 1:], r.cpu().numpy()[:, 1:], rtol=0, atol=0)   # frames are batch-independent: identical
+
+
+def test_shipped_params_json_resolves_or_fails_with_instructions(tmp_path, monkeypatch, capsys):
+    """`python -m realtimeobjectdetection_amd detect` out of the box: the cfg params.json names is generated when missing,
+    a missing weights file stops with instructions (or is synthesised on request), a missing image directory is named."""
+    from realtimeobjectdetection_amd.__main__ import configure_json, resolve_inputs, main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = configure_json(os.path.join(root, "params.json"))["detector_params"]
+    assert int(p["yolo_version"]) == 3 and os.path.basename(p["cfg_file_path"]) in cfgs.SHIPPED
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(SystemExit) as e:
+        resolve_inputs(dict(p))
+    assert "--synthetic-weights" in str(e.value) and os.path.exists(p["cfg_file_path"])       # cfg generated, weights explained
+    assert build_ir(parse_cfg_text(open(p["cfg_file_path"]).read()), 608).n_weights == 62001757
+    q = dict(p, cfg_file_path="./cfg/yolov3-tiny.cfg", weights_file_path="./weights/tiny.weights", resolution=416)
+    with pytest.raises(SystemExit) as e:
+        resolve_inputs(q, synthetic_weights=True)
+    assert "images_path" in str(e.value)
+    assert os.path.getsize("./weights/tiny.weights") == 20 + 4 * 8858734
+    with pytest.raises(SystemExit) as e:
+        main(["train"])
+    assert "out of scope" in str(e.value)
+
+
+def test_bench_self_launch_starts_ranks_without_touching_the_gpu_in_the_parent():
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun): the parent must start one child per GPU and relay the
+    failure of a rank.  Without a GPU here every rank stops at 'needs a GPU'; the parent exits non-zero, never hangs."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher (on a GPU box bench.py itself is run)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") >= 1 and "rank" in r.stderr
+    assert r.stdout.strip() == ""

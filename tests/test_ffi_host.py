@@ -158,3 +158,49 @@ def test_fused_pointwise_accounting_in_split_plans():
     assert flops == ir.conv_flops
     assert hosts == [1] and empty == [2]
     lib.rtod_plan_destroy(h)
+
+
+def test_plan_options_are_explicit_state_not_environment(monkeypatch):
+    """Fusion / kernel-selection switches are per-plan options (rtod_plan_set_option); environment variables that earlier
+    builds honoured are ignored by the product library.  A refused option leaves the plan as it was."""
+    lib = _ffi.lib()
+    for var in ("RTOD_NO_PW", "RTOD_NO_STEM", "RTOD_NO_BAND", "RTOD_NO_AUTOTUNE", "RTOD_DBG_ZERO", "RTOD_F16S3_VARIANT", "RTOD_CONV_VARIANT"):
+        monkeypatch.setenv(var, "1")
+
+    def kinds(h):
+        info = _ffi.PlanInfo()
+        assert lib.rtod_plan_get_info(h, C.byref(info)) == 0
+        out = []
+        for i in range(info.n_launches):
+            li = _ffi.LaunchInfo()
+            assert lib.rtod_plan_get_launch(h, i, C.byref(li)) == 0
+            out.append(li)
+        return out
+
+    rc, h = _plan(cfgs.yolov3_cfg(classes=3), 416)
+    assert rc == 0
+    base = kinds(h)
+    assert [li.kind for li in base].count(7) == 1 and not ({1, 3, 5, 6} & {li.kind for li in base})    # env ignored: stem kernel, all fused
+    assert lib.rtod_plan_set_precision(h, 1) == 0
+    assert any(li.fused_pointwise for li in kinds(h))                                                # RTOD_NO_PW ignored
+    assert lib.rtod_plan_set_option(h, b"fuse_pointwise", 0) == 0
+    assert not any(li.fused_pointwise for li in kinds(h))
+    # the split-f16 format has no stand-alone add kernel: refused, plan unchanged
+    before = [(li.layer, li.kind) for li in kinds(h)]
+    assert lib.rtod_plan_set_option(h, b"fuse_shortcut", 0) == -3 and "add" in _ffi.last_error()
+    assert [(li.layer, li.kind) for li in kinds(h)] == before
+    assert lib.rtod_plan_set_option(h, b"no_such_option", 1) == -1
+    assert lib.rtod_plan_set_precision(h, 0) == 0
+    for name in (b"fuse_shortcut", b"fuse_decode", b"zero_copy_concat", b"stem_kernel"):
+        assert lib.rtod_plan_set_option(h, name, 0) == 0, _ffi.last_error()
+    ks = [li.kind for li in kinds(h)]
+    assert ks.count(3) == 23 and ks.count(5) == 3 and ks.count(6) == 4 and ks.count(1) == 1 and 7 not in ks
+    ir = build_ir(parse_cfg_text(cfgs.yolov3_cfg(classes=3)), 416)
+    assert sum(li.flops_per_frame for li in kinds(h)) == ir.conv_flops
+    lib.rtod_plan_destroy(h)
+    # the planner picks the stand-alone kernels by itself when the graph forbids fusion
+    rc, h = _plan(cfgs.mini_fallback_cfg(), 64)
+    assert rc == 0
+    assert {3, 4, 5, 6} <= {li.kind for li in kinds(h)}
+    assert lib.rtod_plan_set_precision(h, 1) == -3
+    lib.rtod_plan_destroy(h)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-layer differential check of two forced split-f16 tile variants (RTOD_F16S3_VARIANT): the first layer whose output
+"""Per-layer differential check of two forced split-f16 tile variants (plan option force_f16s3_variant): the first layer whose output
 differs localises a kernel bug.   python tools/diff_layers.py <variant> [baseline variant = 10]"""
 import os, sys, tempfile, subprocess, json
 sys.path.insert(0, os.getcwd())
@@ -8,11 +8,10 @@ from realtimeobjectdetection_amd import cfgs, synth
 from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
 from realtimeobjectdetection_amd.darknet import Darknet
 def run(variant):
-    os.environ["RTOD_F16S3_VARIANT"] = str(variant)
     cfg_text = cfgs.yolov3_cfg(); ir = build_ir(parse_cfg_text(cfg_text), 416)
     d = tempfile.mkdtemp()
     m = Darknet(cfgs.write_cfg(os.path.join(d, "v3.cfg"), cfg_text), True).eval()
-    m.net_info["height"] = 416; m.precision = "f16s3"
+    m.net_info["height"] = 416; m.precision = "f16s3"; m.options["force_f16s3_variant"] = int(variant)
     m.load_weight_stream(synth.synth_weights(ir)); m.keep_all_layers = True
     x = torch.from_numpy(synth.synth_frames(2, 416)).cuda()
     with torch.no_grad(): y = m(x).clone()
