@@ -329,7 +329,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         step(0, S1);
         if (t + 1 < nsteps) step(1, S0);
     }
+    // drain: the trailing loads' destination registers must stay allocated until they have landed (see conv_igemm_f16s3.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_regs(S0.bh); tie_regs(S0.bl); tie_regs(S1.bh); tie_regs(S1.bl); tie_regs(BRh); tie_regs(BRl);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     RTOD_STAMP(6)                                              // 6: drain
 

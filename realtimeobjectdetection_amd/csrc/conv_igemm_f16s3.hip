@@ -263,7 +263,14 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         __syncthreads();
         RTOD_GSTAMP(4)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing zero-chunk loads
+    // Drain the trailing zero-chunk loads.  Their destination registers are dead to the compiler from the moment the
+    // last gload statement ends, and register-only epilogue code (address arithmetic, hoisted above this asm: "memory"
+    // orders memory operations only) may be allocated into them — a load landing afterwards then zeroes a live pointer
+    // (observed: 'Memory access fault on address (nil)' once the epilogue's code changed).  wait_stage names every
+    // register of a set as in/out, so both sets stay allocated until the loads have landed.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_stage(S0);
+    wait_stage(S1);
     RTOD_GSTAMP(5)                                    // 5: drain
 
 #ifdef RTOD_STAMPS

@@ -623,3 +623,34 @@ def test_forward_is_capturable_after_autotune(tmp_path_factory):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, want)
+
+
+def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
+    """Autotune may pick any tile of a kernel family for a layer, per batch size: every candidate must produce the same
+    bits (same K order, same MFMA shape).  Forces each split-f16 tile variant in turn (generic implicit-GEMM tiles 0-11
+    on the non-band layers, band tiles 50-58 on the band layers) — this also launches every instantiation, including
+    the ones autotune rarely picks."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    res = 416
+    cfg_text = NETS["yolov3"]()
+    d = tmp_path_factory.mktemp("variants")
+    cfg_path = cfgs.write_cfg(str(d / "yolov3.cfg"), cfg_text)
+    w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
+    x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
+    ref = None
+    for v in list(range(12)) + list(range(50, 59)):
+        m = Darknet(cfg_path, True).eval()
+        m.net_info["height"] = res
+        m.precision = "f16s3"
+        m.autotune = False
+        m.options["force_f16s3_variant"] = v
+        m.load_weight_stream(w)
+        with torch.no_grad():
+            y = m(x)
+        torch.cuda.synchronize()
+        assert not m.overflowed()
+        if ref is None:
+            ref = y.clone()
+        else:
+            assert torch.equal(y, ref), v
+        del m
