@@ -100,6 +100,7 @@ int rtod_plan_set_precision(rtod_plan* plan, int mode);
  *   "zero_copy_concat"  route producers (src/darknet.py:270-290) write into the concat buffer; 0: copy kernels
  *   "stem_kernel"       dedicated NCHW-reading kernel for layer 0; 0: input pack + generic conv
  *   "band_kernel"       LDS-band kernel for 3x3 stride-1 layers; 0: generic implicit GEMM
+ *   "ring_kernel"       persistent LDS-DMA ring tiles among the autotune candidates (bit-identical to the generic tiles)
  *   "force_f16s3_variant" / "force_f32_variant"   >= 0: one tile variant for every conv (tests, A/B runs)
  * Options that leave a cfg inexpressible in the split-f16 format return RTOD_E_CFG when precision is 1. */
 int rtod_plan_set_option(rtod_plan* plan, const char* name, int value);

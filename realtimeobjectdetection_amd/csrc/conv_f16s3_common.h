@@ -64,9 +64,13 @@ constexpr int epi_row_group(int bm, int wm, int rg_max) {
 // KG = 2 (in-workgroup split-K, conv_band_f16s3.hip): NT counts both wave groups, `tid` is the workgroup-wide thread
 // index, wm / wn are positions inside the group `kg`; group 1 deposits its raw accumulators in the tile first and
 // group 0 adds its own before scale / bias / activation.
-template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int KG = 1>
+// PRE: the caller hands over bias[n] / inv_scale[n] of its WN / 16 column groups in registers (conv_ring_f16s3.hip loads them at
+// the start of a tile: a compiler-visible global load inside the epilogue would be waited for with vmcnt(0), which also
+// drains the LDS-DMA ring that is prefetching the next tile).
+template <int BM, int BN, int WM, int WN, int NT, int EPI, int SMEM_BYTES, int KG = 1, bool PRE = false>
 __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                                    int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M, int kg = 0) {
+                                                    int bm, int bn, int tid, int wm, int wn, int lr, int lh, int M, int kg = 0,
+                                                    const float* pre_bias = nullptr, const float* pre_inv = nullptr) {
     constexpr int MT = 16, TM = WM / MT, TN = WN / MT, NE = 4;
     constexpr bool PW = EPI == EPI_SPLIT_PW || EPI == EPI_SPLIT_RES_PW;
     constexpr bool RES = EPI == EPI_SPLIT_RES || EPI == EPI_SPLIT_RES_PW;
@@ -148,8 +152,9 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
             for (int j = 0; j < TN; ++j) {
                 const int nl = wn * WN + j * MT + lr;
                 const int n = bn * BN + nl;
-                const float bias = (n < a.Cout ? a.bias[n] : 0.f) * escale;
-                const float inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale;
+                float bias, inv;
+                if constexpr (PRE) { bias = pre_bias[j] * escale; inv = pre_inv[j] * escale; }
+                else { bias = (n < a.Cout ? a.bias[n] : 0.f) * escale; inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale; }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

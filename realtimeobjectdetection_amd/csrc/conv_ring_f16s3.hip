@@ -13,8 +13,9 @@
 //     at no register cost.  The LDS image is lane-linear per instruction; the 16-byte-chunk XOR swizzle that keeps the
 //     fragment reads conflict-free is applied on the per-lane SOURCE address (cdna guide 5.4 rule 21);
 //   * workgroups are persistent: a workgroup walks its tiles (XCD-aware tile order) and the ring runs ACROSS tile
-//     boundaries — the first stages of tile t+1 are in flight while tile t's epilogue transposes and stores through its own
-//     LDS region.  Nothing lives in registers across the epilogue (the failure mode of the register-staged attempt);
+//     boundaries — the first stages of tile t+1 are in flight while tile t's epilogue transposes and stores through the one
+//     ring slot the loader does not own at that moment.  No load result lives in registers across the epilogue (the failure
+//     mode of the register-staged attempt);
 //   * one s_barrier per k32 step: wait for this wave's own DMA pieces of the step (counted vmcnt), barrier (everybody's
 //     pieces landed, everybody finished reading the slot that is recycled next), issue the DMA STAGES-1 steps ahead, then
 //     fragments + MFMAs.
@@ -42,25 +43,27 @@ template <int N> __device__ __forceinline__ void ring_wait_vmcnt() {
 // Two LDS-DMA pieces (the hi and the lo plane of the same 16 rows): lane l's 16 bytes land at lds + 16*l.  M0 carries the
 // LDS byte address and is written in the statement that uses it (the compiler does not preserve M0 around asm; cdna guide
 // 5.7); s_nop 0: SALU write of M0 -> LDS-DMA read of M0.  voffset >= the descriptor's extent writes zeros.
-__device__ __forceinline__ void dma_pair(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soff_hi, unsigned soff_lo,
-                                         unsigned lds_hi, unsigned lds_lo) {
+__device__ __forceinline__ void dma_pair(const __amdgpu_buffer_rsrc_t rsrc_hi, const __amdgpu_buffer_rsrc_t rsrc_lo, unsigned voffset,
+                                         unsigned soff_hi, unsigned soff_lo, unsigned lds_hi, unsigned lds_lo) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
         "s_mov_b32 m0, %6\n\t"
         "s_nop 0\n\t"
         "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %5 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voffset), "s"(rsrc), "s"(soff_hi), "s"(soff_lo), "s"(lds_hi), "s"(lds_lo)
+        : "v"(voffset), "s"(rsrc_hi), "s"(rsrc_lo), "s"(soff_hi), "s"(soff_lo), "s"(lds_hi), "s"(lds_lo)
         : "memory");
 }
 
 // BM x BN workgroup tile, NWM x NWN waves of (BM/NWM) x (BN/NWN).  STAGES ring slots of one k32 step each.
-// LDS: [STAGES][A hi BM x 64 B | A lo | B hi BN x 64 B | B lo] then the epilogue's transpose tile (EPI_BYTES).
+// LDS: [STAGES][A hi BM x 64 B | A lo | B hi BN x 64 B | B lo].  The epilogue's transpose tile is the ring slot the last
+// K step has just been computed from: the loader runs STAGES-1 steps ahead, so exactly that slot is free until the
+// next tile's first barrier.
 template <int BM, int BN, int NWM, int NWN, int STAGES, int MINW, int EPI>
 __global__ __launch_bounds__(NWM * NWN * 64, MINW)
 void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
@@ -68,16 +71,17 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int PANEL_A = BM * 64, PANEL_B = BN * 64, STAGE = 2 * PANEL_A + 2 * PANEL_B;
-    // DMA work of one stage: row blocks of 16 rows (one 1 KiB piece per plane), A blocks first; every wave takes RBW of them
-    constexpr int RB_A = BM / 16, RB_B = BN / 16, RB = RB_A + RB_B;
-    static_assert(RB % NW == 0, "row blocks must split evenly over the waves (constant vmcnt per step)");
-    constexpr int RBW = RB / NW, LPW = 2 * RBW;                 // row blocks / DMA instructions per wave and step
+    // DMA work of one stage: row blocks of 16 rows (one 1 KiB piece per plane).  Every wave takes A_PER blocks of A and B_PER
+    // of B (block = wave + j*NW); where the blocks do not divide evenly a wave re-issues another valid block (block index
+    // modulo the count: the same bytes land on the same LDS addresses twice), so that every wave issues exactly LPW DMA
+    // instructions per step and one vmcnt literal serves all.
+    constexpr int RB_A = BM / 16, RB_B = BN / 16;
+    constexpr int A_PER = (RB_A + NW - 1) / NW, B_PER = (RB_B + NW - 1) / NW, LPW = 2 * (A_PER + B_PER);
     static_assert((STAGES - 2) * LPW <= 24 && STAGES >= 3, "vmcnt literals / ring depth");
-    constexpr int RING = STAGES * STAGE;
-    constexpr int EPI_BYTES = (WM * (BN + 4) + (EPI == EPI_SPLIT_PW || EPI == EPI_SPLIT_RES_PW ? WM * (PW_MAX_COUT + 4) : 0)) * 4;
+    static_assert(EPI != EPI_SPLIT_PW && EPI != EPI_SPLIT_RES_PW, "no fused pointwise epilogue in this kernel");
+    static_assert(STAGE >= WM * BN * 4, "a ring slot must hold one epilogue pass (WM rows x BN floats)");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const tsm = smem + RING;                      // epilogue transpose tile: never touched by the DMA ring
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -85,7 +89,6 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int n_tiles = grid_m * grid_n;
     const unsigned PS = (unsigned)a.in_ldc * 4u;                 // bytes per pixel (hi plane + lo plane)
     const unsigned lo_plane = (unsigned)a.in_ldc * 2u;
-    const unsigned wlo = 0u;                                     // weight lo plane: its own descriptor
     const int nk = a.Kpad / HBK;
     const int hw = a.Ho * a.Wo;
 
@@ -96,7 +99,7 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     // tile sequence of this workgroup: t = blockIdx.x, + gridDim.x, ...; XCD-aware bijective remap of the tile index
     // (workgroups b and b + 8 share an XCD / L2: XCD x takes a contiguous range of tiles, neighbours share A row panels)
-    auto tile_of = [&](int t, int& bm, int& bn) {
+    auto tile_of = [&](int t, int& bm, int& bn) __attribute__((always_inline)) {
         const int q = n_tiles >> 3, r = n_tiles & 7, xcd = t & 7;
         const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
         bm = u / grid_n; bn = u - bm * grid_n;
@@ -108,63 +111,51 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     const int lchunk = (lane & 3) ^ ((lrow >> 1) & 3);
     int ld_tile = blockIdx.x;                                    // tile the loader is in (may run ahead of the consumer's)
     int ld_kc = 0, ld_c0 = 0, ld_ky = 0, ld_kx = 0;             // K-chunk cursor inside that tile (wave-uniform)
-    unsigned pb[RBW]; int iy0[RBW], ix0[RBW];                   // A blocks: pixel origin; B blocks: weight row offset in pb
-    auto loader_enter_tile = [&]() {
-        int bm, bn;
-        tile_of(ld_tile < n_tiles ? ld_tile : 0, bm, bn);
-        const bool live = ld_tile < n_tiles;
+    unsigned pa[A_PER]; int iy0[A_PER], ix0[A_PER];             // A blocks: byte offset of the receptive-field corner, its coordinates
+    unsigned pw_[B_PER];                                         // B blocks: byte offset of the weight row
+    int blk_a[A_PER], blk_b[B_PER];                              // wave-uniform block ids
 #pragma unroll
-        for (int j = 0; j < RBW; ++j) {
-            const int blk = wave + j * NW;                       // wave-uniform: A / B decided without divergence
-            if (blk < RB_A) {
-                const int m = bm * BM + blk * 16 + lrow;
-                if (live && m < M) {
-                    const int b = m / hw, r = m - b * hw;
-                    const int oy = r / a.Wo, ox = r - oy * a.Wo;
-                    iy0[j] = oy * a.stride - a.pad; ix0[j] = ox * a.stride - a.pad;
-                    pb[j] = (unsigned)((b * a.Hi + iy0[j]) * a.Wi + ix0[j]) * PS + (unsigned)(a.in_coff + lchunk * 8) * 2u;
-                } else { iy0[j] = -(1 << 28); ix0[j] = 0; pb[j] = OOB; }
-            } else {
-                const int n = bn * BN + (blk - RB_A) * 16 + lrow;
-                iy0[j] = 0; ix0[j] = 0;
-                pb[j] = (live && n < a.Cout + 0 * BN) ? (unsigned)(n * a.Kpad + lchunk * 8) * 2u : OOB;
-                if (live && n >= ((a.Cout + 15) / 16) * 16) pb[j] = OOB;
-            }
+    for (int j = 0; j < A_PER; ++j) blk_a[j] = (wave + j * NW) % RB_A;
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) blk_b[j] = (wave + j * NW) % RB_B;
+    auto loader_enter_tile = [&]() __attribute__((always_inline)) {
+        int bm, bn;
+        const bool live = ld_tile < n_tiles;
+        tile_of(live ? ld_tile : 0, bm, bn);
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int m = bm * BM + blk_a[j] * 16 + lrow;
+            const bool ok = live && m < M;
+            const int mm = ok ? m : 0;
+            const int b = mm / hw, r = mm - b * hw;
+            const int oy = r / a.Wo, ox = r - oy * a.Wo;
+            iy0[j] = ok ? oy * a.stride - a.pad : -(1 << 28);
+            ix0[j] = ox * a.stride - a.pad;
+            pa[j] = (unsigned)((b * a.Hi + iy0[j]) * a.Wi + ix0[j]) * PS + (unsigned)(a.in_coff + lchunk * 8) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int n = bn * BN + blk_b[j] * 16 + lrow;
+            pw_[j] = live ? (unsigned)(n * a.Kpad + lchunk * 8) * 2u : OOB;      // rows >= Npad fall outside the descriptor: zeros
         }
         ld_kc = 0; ld_c0 = 0; ld_ky = 0; ld_kx = 0;
     };
     // issue this wave's pieces of the next stage into ring slot `slot`, advance the cursor (to the next tile at the end of K)
-    auto loader_issue = [&](int slot) {
-        const bool live = ld_tile < n_tiles;
+    auto loader_issue = [&](int slot) __attribute__((always_inline)) {
         const unsigned tap_off = (unsigned)(ld_ky * a.Wi + ld_kx) * PS + (unsigned)ld_c0 * 2u;
         const unsigned koff = (unsigned)ld_kc * (HBK * 2);
         const unsigned sbase = lds0 + (unsigned)slot * STAGE;
 #pragma unroll
-        for (int j = 0; j < RBW; ++j) {
-            const int blk = wave + j * NW;
-            if (blk < RB_A) {
-                const bool ok = live && (unsigned)(iy0[j] + ld_ky) < (unsigned)a.Hi && (unsigned)(ix0[j] + ld_kx) < (unsigned)a.Wi;
-                const unsigned vo = ok ? pb[j] + tap_off : OOB;
-                const unsigned l = sbase + (unsigned)blk * 1024u;
-                dma_pair(rs_a, vo, 0u, lo_plane, l, l + PANEL_A);
-            } else {
-                const unsigned vo = live ? pb[j] : OOB;
-                const unsigned l = sbase + 2u * PANEL_A + (unsigned)(blk - RB_A) * 1024u;
-                // hi and lo weight planes are separate allocations: two descriptors, same offsets
-                unsigned keep;
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %5\n\t"
-                    "s_nop 0\n\t"
-                    "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
-                    "s_mov_b32 m0, %6\n\t"
-                    "s_nop 0\n\t"
-                    "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-                    "s_mov_b32 m0, %0"
-                    : "=&s"(keep)
-                    : "v"(vo), "s"(rs_wh), "s"(rs_wl), "s"(koff + wlo), "s"(l), "s"(l + PANEL_B)
-                    : "memory");
-            }
+        for (int j = 0; j < A_PER; ++j) {
+            const bool ok = (unsigned)(iy0[j] + ld_ky) < (unsigned)a.Hi && (unsigned)(ix0[j] + ld_kx) < (unsigned)a.Wi;
+            const unsigned vo = ok ? pa[j] + tap_off : OOB;
+            const unsigned l = sbase + (unsigned)blk_a[j] * 1024u;
+            dma_pair(rs_a, rs_a, vo, 0u, lo_plane, l, l + PANEL_A);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const unsigned l = sbase + 2u * PANEL_A + (unsigned)blk_b[j] * 1024u;
+            dma_pair(rs_wh, rs_wl, pw_[j], koff, koff, l, l + PANEL_B);           // hi and lo weight planes: two allocations
         }
         ++ld_kc;
         if (++ld_kx == a.kw) { ld_kx = 0; if (++ld_ky == a.kh) { ld_ky = 0; ld_c0 += HBK; } }
@@ -192,10 +183,22 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+        // bias / inv_scale of this wave's column groups, loaded and WAITED FOR here: the compiler's wait for a global load
+        // is a vmcnt that also covers every DMA piece issued before it; at the start of a tile that only waits for stages
+        // this tile needs next, inside the epilogue it would drain the ring that is prefetching the next tile
+        float ebias[TN], einv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn * BN + wn * WN + j * 16 + lr;
+            ebias[j] = n < a.Cout ? a.bias[n] : 0.f;
+            einv[j] = n < a.Cout ? a.inv_scale[n] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(ebias[j]), "+v"(einv[j]));
 
 #pragma unroll 1
         for (int kc = 0; kc < nk; ++kc) {
-            ring_wait_vmcnt<(STAGES - 2) * LPW>();               // this wave's pieces of the current step have landed
+            ring_wait_vmcnt<(STAGES - 2) * LPW>();               // this wave's pieces of the current step have landed (the younger STAGES-2 stages may stay in flight)
             __builtin_amdgcn_s_barrier();                        // ... and everybody's; the previous step's slot is free
             {
                 const int prev = slot == 0 ? STAGES - 1 : slot - 1;
@@ -223,9 +226,14 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                 }
             slot = slot + 1 == STAGES ? 0 : slot + 1;
         }
-        // epilogue through the private transpose region: the ring keeps filling for the next tile meanwhile
-        conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, EPI_BYTES>(a, acc, tsm, bm, bn, tid, wm, wn, lr, lh, M);
-        __builtin_amdgcn_s_barrier();                            // transpose tile free again before the next tile's epilogue
+        // epilogue: the slot just consumed is the only one the loader does not own (it is refilled after the next tile's
+        // first barrier); the other STAGES-1 slots keep filling for the next tile meanwhile
+        {
+            const int done = slot == 0 ? STAGES - 1 : slot - 1;
+            __builtin_amdgcn_s_barrier();                        // every wave has read its last fragments from that slot
+            conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, STAGE, 1, true>(a, acc, smem + done * STAGE, bm, bn, tid, wm, wn, lr, lh, M, 0, ebias, einv);
+        }
+        __builtin_amdgcn_s_barrier();                            // transpose reads done before the slot is handed back to the loader
     }
     ring_wait_vmcnt<0>();                                        // trailing (out-of-range) pieces: nothing may be in flight at exit
 }
@@ -233,8 +241,8 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
 //   X(mode, BM, BN, waves along M, waves along N, STAGES, MINW, workgroups per CU)
 #define RTOD_RING_TILES(X) \
-    X(0, 64, 128, 2, 2, 3, 2, 2) X(1, 128, 128, 4, 2, 4, 2, 1) X(2, 64, 64, 2, 2, 4, 2, 2) X(3, 128, 64, 4, 2, 4, 2, 2) \
-    X(4, 32, 128, 1, 4, 4, 2, 2) X(5, 96, 128, 2, 2, 3, 2, 1)
+    X(0, 64, 128, 2, 2, 3, 2, 2) X(1, 128, 128, 4, 2, 4, 2, 1) X(2, 64, 64, 2, 2, 4, 2, 2) X(3, 128, 64, 4, 2, 3, 4, 2) \
+    X(4, 32, 128, 1, 4, 4, 2, 2) X(5, 192, 128, 4, 2, 3, 2, 1) X(6, 96, 128, 2, 4, 5, 2, 1) X(7, 128, 128, 4, 2, 5, 2, 1)
 
 #define RTOD_X_INFO(mode, bm, bn, nwm, nwn, st, minw, wpc) {bm, bn, "conv_ring_f16s3<" #bm "x" #bn "," #nwm "x" #nwn ",s" #st ">"},
 static const ConvVariantInfo kRingModes[RING_MODES] = { RTOD_RING_TILES(RTOD_X_INFO) };
@@ -251,13 +259,11 @@ int conv_ring_kernel_name(int mode, int epi, char* buf, size_t len) {
 
 template <int BM, int BN, int NWM, int NWN, int STAGES, int MINW, int WPC>
 static int launch_ring(const ConvArgs& a, hipStream_t s) {
-    constexpr int WM = BM / NWM;
     constexpr int NT = NWM * NWN * 64;
     const int M = a.B * a.Ho * a.Wo;
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
     const bool pw = a.pw_wh != nullptr;
-    const int epi_bytes = (WM * (BN + 4) + (pw ? WM * (PW_MAX_COUT + 4) : 0)) * 4;
-    const int lds = STAGES * (2 * BM * 64 + 2 * BN * 64) + epi_bytes;
+    const int lds = STAGES * (2 * BM * 64 + 2 * BN * 64);
     if (lds > 160 * 1024) { set_error("conv_ring_f16s3: %d bytes of LDS", lds); return RTOD_E_ARG; }
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

@@ -282,6 +282,7 @@ int Plan::set_option(const char* name, int value) {
     const std::string k(name);
     bool* flag = nullptr; int* num = nullptr;
     if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
+    else if (k == "ring_kernel") flag = &opt_ring_kernel;
     else if (k == "stem_kernel") flag = &opt_stem_kernel;
     else if (k == "band_kernel") flag = &opt_band_kernel;
     else if (k == "fuse_shortcut") flag = &opt_fuse_shortcut;
@@ -721,6 +722,10 @@ int Plan::choose_variant(const Layer& L, int batch) const {
 }
 
 int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
+    if (v >= RING_VARIANT_BASE) {
+        if (pc.band) { set_error("ring variant requested for a band layer"); return RTOD_E_STATE; }
+        return launch_conv_ring_f16s3(a, v - RING_VARIANT_BASE, s);
+    }
     if (v >= BAND_VARIANT_BASE) {
         if (!pc.band) { set_error("band variant requested for a layer without band weights"); return RTOD_E_STATE; }
         return launch_conv_band_f16s3(a, v - BAND_VARIANT_BASE, s);
@@ -809,6 +814,12 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
             if (pw && vi.bn < L.cout) continue;                                       // fused pointwise: one N tile
             cand.push_back(v);
         }
+        if (!pw && opt_ring_kernel)
+            for (int m = 0; m < RING_MODES; ++m) {
+                const ConvVariantInfo& vi = conv_ring_mode_info(m);
+                if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;
+                cand.push_back(RING_VARIANT_BASE + m);
+            }
     }
     int best_v = variant_for(l, batch);
     int rc = RTOD_OK;
@@ -859,6 +870,7 @@ int Plan::variant_for(const Launch& l, int batch) const {
         const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
+        if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active())) return v;
         const int g = choose_variant_f16s3(layers[l.layer], batch);
         if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;
         return g;

@@ -86,6 +86,7 @@ struct Plan {
     bool opt_fuse_pointwise = true;   // run a 1x1 conv in the previous conv's epilogue where the plan allows it
     bool opt_stem_kernel = true;      // dedicated NCHW-reading kernel for layer 0 (else pack + generic conv)
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
+    bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
     bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
     bool opt_fuse_decode = true;      // head decode in the head conv's epilogue (else stand-alone decode kernel)
     bool opt_zero_copy_concat = true; // route producers write straight into the concat buffer (else copy kernels)

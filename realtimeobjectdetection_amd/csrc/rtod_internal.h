@@ -117,7 +117,14 @@ int conv_band_default_mode(int cin, int h, int w);
 const ConvVariantInfo& conv_band_mode_info(int mode);
 int conv_band_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_band_f16s3(const ConvArgs& a, int mode, hipStream_t s);
-constexpr int BAND_VARIANT_BASE = 50;      // variant ids >= this select the band kernel: BAND_VARIANT_BASE + mode
+constexpr int BAND_VARIANT_BASE = 50;      // variant ids in [50, 70) select the band kernel: BAND_VARIANT_BASE + mode
+// Persistent LDS-DMA ring kernel (conv_ring_f16s3.hip): same K order and MFMA sequence as the generic implicit GEMM, so
+// its tiles are further autotune candidates for every layer the generic kernel runs (bit-identical results).
+constexpr int RING_MODES = 8;
+constexpr int RING_VARIANT_BASE = 70;      // variant ids >= this: RING_VARIANT_BASE + mode
+const ConvVariantInfo& conv_ring_mode_info(int mode);
+int conv_ring_kernel_name(int mode, int epi, char* buf, size_t len);
+int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);

@@ -548,7 +548,7 @@ def test_unfused_plan_options_vs_oracle(tmp_path_factory):
         want = ref.forward(x).numpy()
     for tag in outs:
         assert rel_err(outs[tag], want).max() <= TOL, tag
-    assert rel_err(outs["fused"], outs["unfused"]).max() <= 2e-5
+    assert rel_err(outs["fused"], outs["unfused"]).max() <= 5e-5          # different stem kernels: another summation order
 
 
 # ------------------------------------------------------------------------------- split-f16 range guard
@@ -628,8 +628,8 @@ def test_forward_is_capturable_after_autotune(tmp_path_factory):
 def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     """Autotune may pick any tile of a kernel family for a layer, per batch size: every candidate must produce the same
     bits (same K order, same MFMA shape).  Forces each split-f16 tile variant in turn (generic implicit-GEMM tiles 0-11
-    on the non-band layers, band tiles 50-58 on the band layers) — this also launches every instantiation, including
-    the ones autotune rarely picks."""
+    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-58 on the band layers) — this also
+    launches every instantiation, including the ones autotune rarely picks."""
     from realtimeobjectdetection_amd.darknet import Darknet
     res = 416
     cfg_text = NETS["yolov3"]()
@@ -638,7 +638,7 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
     x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
     ref = None
-    for v in list(range(12)) + list(range(50, 59)):
+    for v in list(range(12)) + list(range(50, 59)) + list(range(70, 78)):
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
         m.precision = "f16s3"
