@@ -188,12 +188,12 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=14.0):
     return out
 
 
-def rocprof_kernel_name(variant, epi):
-    """Exact kernel instantiation name rocprofv3 prints for a conv launch (built next to the launch switch in csrc)."""
+def rocprof_kernel_name(model, index):
+    """Exact kernel instantiation name rocprofv3 prints for launch `index` (built next to the launch switch in csrc)."""
     import ctypes as C
     from realtimeobjectdetection_amd import _ffi
     buf = C.create_string_buffer(256)
-    _ffi.check(_ffi.lib().rtod_conv_kernel_name(int(variant), int(epi), buf, 256))
+    _ffi.check(_ffi.lib().rtod_plan_launch_kernel_name(model._plan, int(index), buf, 256))
     return buf.value.decode()
 
 
@@ -210,13 +210,12 @@ def roofline_from_launches(model, x, steps):
     tot /= steps
     lib = _ffi.lib()
     groups = {}
-    for li, ms in zip(infos, tot):
+    for idx, (li, ms) in enumerate(zip(infos, tot)):
         if li.kind != 0 or li.flops_per_frame == 0:      # non-conv launches; 1x1 convs fused into the previous conv's epilogue
             continue
         # group by the exact kernel instantiation rocprofv3 reports (tile variant + epilogue)
         name = lib.rtod_conv_variant_name(li.variant).decode()
-        epi = 2 if li.fused_decode else ((4 if li.fused_residual else 3) if li.fused_pointwise else (1 if li.fused_residual else 0))
-        kname = rocprof_kernel_name(li.variant, epi)
+        kname = rocprof_kernel_name(model, idx)
         g = groups.setdefault(kname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "tile": name})
         g["ms"] += float(ms); g["flops"] += float(li.flops_per_frame) * B; g["launches"] += 1
         g["bytes"] += float(li.bytes_per_frame) * B + float(li.weight_bytes)

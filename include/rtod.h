@@ -86,6 +86,8 @@ const char* rtod_conv_variant_name(int variant);
 /* Demangled name of the kernel instantiation a launch runs (what rocprofv3 --kernel-trace prints): variant from
  * rtod_launch_info, epilogue 0 plain, 1 fused shortcut, 2 fused head decode, 3 / 4 = 0 / 1 with a fused pointwise conv. */
 int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len);
+/* Same for launch `index` of a plan (all context taken from the plan; "" for launches that are not convolution kernels). */
+int rtod_plan_launch_kernel_name(const rtod_plan* plan, int index, char* buf, size_t len);
 /* Arithmetic of the convolutions (call before rtod_plan_load_weights):
  *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-level fmaf chains, the parity anchor;
  *   1  split-precision f16 MFMA: a*w ~= ah*wh + ah*wl + al*wh with fp32 accumulation (22-bit

@@ -44,6 +44,7 @@ SIGNATURES = {
     "rtod_plan_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rtod_conv_variant_name": (C.c_char_p, [C.c_int]),
     "rtod_conv_kernel_name": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "rtod_plan_launch_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "rtod_plan_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "rtod_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rtod_plan_set_overflow_flag": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -92,6 +92,7 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 }
 
 const char* rtod_conv_variant_name(int variant) {
+    if (variant >= 100 + PW_VARIANT_BASE && variant < 100 + PW_VARIANT_BASE + PW_MODES) return conv_pw_mode_info(variant - 100 - PW_VARIANT_BASE).name;
     if (variant >= 100 + RING_VARIANT_BASE && variant < 100 + RING_VARIANT_BASE + RING_MODES) return conv_ring_mode_info(variant - 100 - RING_VARIANT_BASE).name;
     if (variant >= 100 + BAND_VARIANT_BASE && variant < 100 + BAND_VARIANT_BASE + BAND_MODES) return conv_band_mode_info(variant - 100 - BAND_VARIANT_BASE).name;
     if (variant >= 100 && variant < 100 + HV_COUNT) return conv_f16s3_variant_info(variant - 100).name;
@@ -102,12 +103,29 @@ const char* rtod_conv_variant_name(int variant) {
 int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len) {
     if (!buf || len == 0) { set_error("conv_kernel_name: null buffer"); return RTOD_E_ARG; }
     int n = -1;
-    if (variant >= 100 + RING_VARIANT_BASE) n = conv_ring_kernel_name(variant - 100 - RING_VARIANT_BASE, epilogue, buf, len);
+    if (variant >= 100 + PW_VARIANT_BASE) { set_error("conv_kernel_name: pointwise kernels are named per launch (rtod_plan_launch_kernel_name)"); return RTOD_E_ARG; }
+    else if (variant >= 100 + RING_VARIANT_BASE) n = conv_ring_kernel_name(variant - 100 - RING_VARIANT_BASE, epilogue, buf, len);
     else if (variant >= 100 + BAND_VARIANT_BASE) n = conv_band_kernel_name(variant - 100 - BAND_VARIANT_BASE, epilogue, buf, len);
     else if (variant >= 100) n = conv_f16s3_kernel_name(variant - 100, epilogue, buf, len);
     else n = conv_f32_kernel_name(variant, buf, len);
     if (n < 0 || (size_t)n >= len) { set_error("conv_kernel_name: unknown variant %d or buffer too small", variant); return RTOD_E_ARG; }
     return RTOD_OK;
+}
+
+int rtod_plan_launch_kernel_name(const rtod_plan* plan, int index, char* buf, size_t len) {
+    RTOD_GUARD_BEGIN
+    if (!plan || !buf || len == 0 || index < 0 || index >= (int)plan->p.launches.size()) { set_error("launch_kernel_name: bad args"); return RTOD_E_ARG; }
+    rtod_launch_info li;
+    plan->p.fill_launch_info(index, &li, plan->p.tuned.empty() ? plan->p.max_batch : plan->p.tuned.rbegin()->first);
+    buf[0] = 0;
+    if (li.kind != LK_CONV || li.flops_per_frame == 0) return RTOD_OK;                 // non-conv launch / conv hosted by the previous launch: empty name
+    const int epi = li.fused_decode ? 2 : (li.fused_pointwise ? (li.fused_residual ? 4 : 3) : (li.fused_residual ? 1 : 0));
+    int n = -1;
+    if (li.variant >= 100 + PW_VARIANT_BASE) n = conv_pw_kernel_name(li.variant - 100 - PW_VARIANT_BASE, li.cin, buf, len);
+    else return rtod_conv_kernel_name(li.variant, epi, buf, len);
+    if (n < 0 || (size_t)n >= len) { set_error("launch_kernel_name: buffer too small"); return RTOD_E_ARG; }
+    return RTOD_OK;
+    RTOD_GUARD_END
 }
 
 int rtod_plan_set_precision(rtod_plan* plan, int mode) {

@@ -61,6 +61,7 @@ struct PackedConv {
     bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32, or (split) [Cout][32] f16 hi / lo planes + inv_scale
     bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
     bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
+    bool pw = false;                  // runs on conv_pw_f16s3 (stand-alone 1x1 conv, no residual / decode epilogue)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
 };
 
@@ -86,6 +87,7 @@ struct Plan {
     bool opt_fuse_pointwise = true;   // run a 1x1 conv in the previous conv's epilogue where the plan allows it
     bool opt_stem_kernel = true;      // dedicated NCHW-reading kernel for layer 0 (else pack + generic conv)
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
+    bool opt_pw_kernel = true;        // streaming kernel for the stand-alone 1x1 layers it supports
     bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
     bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
     bool opt_fuse_decode = true;      // head decode in the head conv's epilogue (else stand-alone decode kernel)

@@ -33,6 +33,8 @@ from . import _ffi
 from .cfg import parse_cfg, build_ir
 
 
+_OVERFLOW_MSG = ("Darknet (precision f16s3): an activation reached the split-f16 range limit (|x| >= 8188) and was saturated; "
+                 "the results of that forward are not valid. Use precision='fp32' (exact MFMA kernels) for these weights.")
 _pending_overflow = {}      # output data_ptr -> weakref(model): util.write_results reads the model's overflow flag at its host sync
 
 
@@ -345,7 +347,7 @@ class Darknet(nn.Module):
             if self.overflow_check == "forward":
                 if self.overflowed():
                     if self.precision != "auto":
-                        self.check_overflow()
+                        raise FloatingPointError(_OVERFLOW_MSG)
                     warnings.warn("Darknet: an activation left the split-f16 range (|x| >= 8188); precision 'auto' falls back to the "
                                   "exact-fp32 MFMA kernels for this model", RuntimeWarning)
                     self.precision = "fp32"
@@ -367,9 +369,7 @@ class Darknet(nn.Module):
 
     def check_overflow(self):
         if self.overflowed():
-            raise FloatingPointError(
-                "Darknet (precision f16s3): an activation reached the split-f16 range limit (|x| >= 8188) and was saturated; "
-                "the results of that forward are not valid. Use precision='fp32' (exact MFMA kernels) for these weights.")
+            raise FloatingPointError(_OVERFLOW_MSG)
 
     def forward_timed(self, x):
         """Forward with a HIP-event pair around every launch; returns (out, ms per launch)."""
