@@ -336,7 +336,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __syncthreads();
     RTOD_STAMP(6)                                              // 6: drain
 
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     if (a.dbg & 4) return;
 #endif
     conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
@@ -443,7 +443,7 @@ int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (a.in_ldc % 8 || a.in_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin) { set_error("launch_conv_band: bad view / K"); return RTOD_E_ARG; }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_band: buffer extents"); return RTOD_E_ARG; }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_band: input view exceeds its buffer"); return RTOD_E_ARG; }
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;   // diagnostic build only
     if (dbg_zero & 1) a.in_bytes = 1;
     if (dbg_zero & 2) a.w_bytes = 1;

@@ -45,7 +45,7 @@ __device__ __forceinline__ u32x4 asm_buffer_load_b128(const __amdgpu_buffer_rsrc
 // dirty L2 to drain (measured +1.2 % frames/s over plain write-back stores; non-temporal stores: -2.7 %).
 // `plain` (diagnostic build, RTOD_DBG_ZERO bit 8) keeps the write-back store for that comparison.
 __device__ __forceinline__ void store_act16(_Float16* p, const f16x8& v, bool plain) {
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     if (plain) { *reinterpret_cast<f16x8*>(p) = v; return; }
 #endif
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
@@ -87,7 +87,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
     static_assert(RG >= WM && BM % RG == 0, "epilogue row group");
     float* T = reinterpret_cast<float*>(smem);
     const int hw = a.Ho * a.Wo;
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     const bool st_plain = (a.dbg & 8) != 0;
 #else
     constexpr bool st_plain = false;

@@ -273,7 +273,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     wait_stage(S1);
     RTOD_GSTAMP(5)                                    // 5: drain
 
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     if (a.dbg & 4) return;                            // timing experiment: no epilogue
 #endif
     conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, 2 * STAGE>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M);
@@ -366,7 +366,7 @@ int launch_conv_f16s3(const ConvArgs& a_in, int variant, hipStream_t s) {
         set_error("launch_conv_f16s3: buffer of %u / %u bytes outside (0, 2 GiB)", a.in_bytes, a.w_bytes); return RTOD_E_ARG;
     }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_f16s3: input view exceeds its buffer"); return RTOD_E_ARG; }
-#ifdef RTOD_STAMPS
+#ifdef RTOD_DIAG
     // diagnostic build only: timing experiments (cdna guide 7: zero-record descriptors drop the loads of one operand, results are garbage)
     static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;
     if (dbg_zero & 1) a.in_bytes = 1;

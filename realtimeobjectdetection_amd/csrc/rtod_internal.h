@@ -1,6 +1,11 @@
 // Internal declarations shared by the kernels, the plan and the C ABI (not installed).
 #pragma once
 #include <hip/hip_runtime.h>
+// Diagnostic builds (never the product library): -DRTOD_STAMPS = in-kernel s_memtime phase attribution (synchronises after
+// every launch), -DRTOD_DIAG = the RTOD_DBG_ZERO timing knobs alone (zero-record descriptors, skipped epilogue); stamps imply diag.
+#if defined(RTOD_STAMPS) && !defined(RTOD_DIAG)
+#define RTOD_DIAG 1
+#endif
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
