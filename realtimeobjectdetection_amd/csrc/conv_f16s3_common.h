@@ -51,6 +51,91 @@ __device__ __forceinline__ void store_act16(_Float16* p, const f16x8& v, bool pl
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
+// ---- transposed product (out^T = W * act^T): the MFMA's first operand is the weight fragment, the second the activation
+// fragment, so a lane's accumulator holds 4 consecutive output CHANNELS (rows 4*lh + e) of ONE pixel (column lr).  With the
+// weight rows of a 32-channel group interleaved over two 16-row tiles (tr_chan_of_row) the two tiles of a pair give the lane
+// 8 consecutive channels: one 16-byte store per plane straight from the accumulators — no LDS transpose, no barrier.
+// Panel row rho of an N tile (tile t = rho/16, row r = rho%16) <-> channel 32*(t/2) + 8*(r/4) + 4*(t%2) + r%4 of the tile.
+__host__ __device__ __forceinline__ int tr_chan_of_row(int rho) {
+    const int t = rho >> 4, r = rho & 15;
+    return 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3);
+}
+
+// Register epilogue of the transposed product.  acc[i][j]: pixel tile i (16 pixels), channel tile j of the wave.
+// KG == 2 (in-workgroup split-K): group 1 parks its accumulators in LDS (`smem`, 16 bytes per lane and tile: the MFMA layout
+// as it stands), one barrier, group 0 adds them to its own and stores.
+template <int BM, int BN, int WM, int WN, int NTG, bool RES, int KG = 1>
+__device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem,
+                                                         int bm, int bn, int tidg, int wm, int wn, int lr, int lh, int M, int kg = 0) {
+    constexpr int TM = WM / 16, TN = WN / 16, NP = TN / 2;
+    static_assert(TN % 2 == 0, "channel tiles come in pairs");
+    if constexpr (KG == 2) {
+        f32x4* T = reinterpret_cast<f32x4*>(smem);
+        const int base = ((tidg >> 6) * TM * TN) * 64 + (tidg & 63);          // [wave of the group][i][j][lane]
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) T[base + (i * TN + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 o = T[base + (i * TN + j) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += o[e];
+            }
+    }
+    float amax = 0.f;
+    _Float16* const oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff;
+    const _Float16* const rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff;
+#pragma unroll
+    for (int P = 0; P < NP; ++P) {
+        const int c0 = bn * BN + wn * WN + 32 * P + 8 * lh;
+        const bool cok = c0 < a.Cout;                                        // Cout % 8 == 0 for every split-format tensor
+        const int cc = cok ? c0 : 0;
+        // residual operands of this channel group first: their latency runs under the scale / bias loads and the conversions
+        f16x8 rq_h[RES ? TM : 1], rq_l[RES ? TM : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = bm * BM + wm * WM + i * 16 + lr;
+                const bool ok = m < M && cok;
+                const _Float16* q = rh + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + cc;
+                rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        f32x4 iv0 = *reinterpret_cast<const f32x4*>(a.inv_scale + cc), iv1 = *reinterpret_cast<const f32x4*>(a.inv_scale + cc + 4);
+        f32x4 bs0 = *reinterpret_cast<const f32x4*>(a.bias + cc), bs1 = *reinterpret_cast<const f32x4*>(a.bias + cc + 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = bm * BM + wm * WM + i * 16 + lr;
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = e < 4 ? acc[i][2 * P][e] : acc[i][2 * P + 1][e - 4];
+                // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly (power of two)
+                float v = s * ((e < 4 ? iv0[e] : iv1[e - 4]) * SPLIT_SCALE) + (e < 4 ? bs0[e] : bs1[e - 4]) * SPLIT_SCALE;
+                if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+                if constexpr (RES) v += (float)rq_h[i][e] + (float)rq_l[i][e];
+                _Float16 h, l;
+                split_f16(v, h, l, amax);
+                ph[e] = h; pl[e] = l;
+            }
+            if (m < M && cok) {
+                _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c0;
+                store_act16(q, ph, false);
+                store_act16(q + a.out_ldc, pl, false);
+            }
+        }
+    }
+    split_overflow_report(a.ovf, amax);
+}
+
 constexpr int epi_row_group(int bm, int wm, int rg_max) {
     int best = wm;
     for (int r = wm; r <= bm && r <= rg_max; r += wm) if (bm % r == 0) best = r;
@@ -103,13 +188,13 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
         pw_n2t = a.pw_cout / 16;                                  // 1, 2 or 4: divides the wave count
         pw_j = (tid >> 6) % pw_n2t;
         const int n2 = pw_j * 16 + (tid & 15);
-        const _Float16* w2h = a.pw_wh + (int64_t)n2 * a.pw_k + ((tid & 63) >> 4) * 8;
-        const _Float16* w2l = a.pw_wl + (int64_t)n2 * a.pw_k + ((tid & 63) >> 4) * 8;
+        const _Float16* w2h = a.pw_wh + (int64_t)n2 * 32 + ((tid & 63) >> 4) * 8;      // [chunk][pw_npad][32]
+        const _Float16* w2l = a.pw_wl + (int64_t)n2 * 32 + ((tid & 63) >> 4) * 8;
 #pragma unroll
         for (int ks = 0; ks < PWK; ++ks) {
             const bool ok = ks * 32 < a.pw_k;
-            b2h[ks] = ok ? *reinterpret_cast<const f16x8*>(w2h + ks * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            b2l[ks] = ok ? *reinterpret_cast<const f16x8*>(w2l + ks * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            b2h[ks] = ok ? *reinterpret_cast<const f16x8*>(w2h + (int64_t)ks * a.pw_npad * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            b2l[ks] = ok ? *reinterpret_cast<const f16x8*>(w2l + (int64_t)ks * a.pw_npad * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
         bias2 = a.pw_bias[n2] * SPLIT_SCALE; inv2 = a.pw_inv_scale[n2] * SPLIT_SCALE;
     }

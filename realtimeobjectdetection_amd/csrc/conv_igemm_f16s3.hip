@@ -13,7 +13,7 @@
 // range; |activation| must stay < 8188).  Same bytes per pixel as fp32.  Producers (this kernel's
 // epilogue, the stem conv, upsample) write it, so staging an A tile is a pure 16-byte copy exactly
 // like the pre-split weight planes: no conversion VALU in the main loop.
-// Weights: [Npad][Kpad] hi and lo planes, per-output-channel power-of-two pre-scale undone (exactly)
+// Weights: [Kpad/32][Npad][32] hi and lo planes (K-chunk major), per-output-channel power-of-two pre-scale undone (exactly)
 // in the epilogue through inv_scale[n].
 //
 // Main loop: BMxBNx32 per stage = one k32 step of 16x16x32 MFMAs (the shape the chip clocks highest on, and
@@ -101,7 +101,8 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     unsigned wbase[B_SLOTS];
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i)
-        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u : OOB;
+        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + row0 + i * RPP) * 32 + c16 * 8) * 2u : OOB;
+    const unsigned wchunk = (unsigned)a.Npad * (HBK * 2);        // bytes of one K-chunk panel of a weight plane
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
@@ -124,7 +125,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             S.ah[i] = asm_buffer_load_b128(rs_a, vo, 0u);
             S.al[i] = asm_buffer_load_b128(rs_a, vo, lo_plane);
         }
-        const unsigned koff = (unsigned)ld_kc * (HBK * 2);
+        const unsigned koff = (unsigned)ld_kc * wchunk;
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const unsigned wo = live ? wbase[i] : OOB;

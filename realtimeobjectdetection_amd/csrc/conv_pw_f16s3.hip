@@ -32,12 +32,8 @@ constexpr int PW_WAVES = 12, PW_NT = PW_WAVES * 64;         // 192 pixels per wo
 constexpr int PW_DEPTH = 4;                                 // 64-channel activation segments in flight per wave
 constexpr int PW_TABLE = 2 * 128 * 4;                       // inv_scale / bias table (BN <= 128 floats each)
 
-// panel row rho (tile t = rho/16, row r = rho%16) <-> output channel of the slice: pairs of tiles interleave a 32-channel
-// group so that accumulator rows 4*lh + e of tiles 2P and 2P+1 are channels 32P + 8*lh + {0..3} and {4..7}
-__device__ __forceinline__ int pw_chan_of_row(int rho) {
-    const int t = rho >> 4, r = rho & 15;
-    return 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3);
-}
+// panel row rho <-> output channel of the slice: tr_chan_of_row (conv_f16s3_common.h)
+__device__ __forceinline__ int pw_chan_of_row(int rho) { return tr_chan_of_row(rho); }
 
 __device__ __forceinline__ void pw_dma_pair(const __amdgpu_buffer_rsrc_t rsrc_hi, const __amdgpu_buffer_rsrc_t rsrc_lo, unsigned voffset,
                                             unsigned soff, unsigned lds_hi, unsigned lds_lo) {
@@ -116,9 +112,9 @@ void conv_pw_f16s3_kernel(const ConvArgs a, const int gm, const int n_strips) {
             const int rho = rb * 16 + lrow;
             const int c = (lane & 3) ^ ((rho >> 1) & 3);
             const int n = n0 + pw_chan_of_row(rho);
-            const unsigned vo = (unsigned)(n * a.Kpad + c * 8) * 2u;     // rows >= Npad: outside the descriptor -> zeros
+            const unsigned vo = (unsigned)(n * 32 + c * 8) * 2u;         // K-chunk major planes: [chunk][Npad][32]
             const unsigned l = lds0 + (unsigned)(kc * 2 * PANEL + rb * 1024);
-            pw_dma_pair(rs_wh, rs_wl, vo, (unsigned)kc * 64u, l, l + PANEL);
+            pw_dma_pair(rs_wh, rs_wl, vo, (unsigned)kc * (unsigned)a.Npad * 64u, l, l + PANEL);
         }
         for (int i = tid; i < BN; i += PW_NT) {
             const int n = n0 + i;

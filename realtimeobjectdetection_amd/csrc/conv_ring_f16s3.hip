@@ -80,6 +80,9 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     static_assert((STAGES - 2) * LPW <= 24 && STAGES >= 3, "vmcnt literals / ring depth");
     static_assert(EPI != EPI_SPLIT_PW && EPI != EPI_SPLIT_RES_PW, "no fused pointwise epilogue in this kernel");
     static_assert(STAGE >= WM * BN * 4, "a ring slot must hold one epilogue pass (WM rows x BN floats)");
+    // split-format outputs: transposed product + register epilogue (conv_f16s3_common.h); the head decode keeps the
+    // pixel-major accumulator and the LDS-transposed epilogue (its rows are 255 contiguous floats)
+    constexpr bool TRANSPOSED = EPI != EPI_DECODE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -135,15 +138,16 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int n = bn * BN + blk_b[j] * 16 + lrow;
-            pw_[j] = live ? (unsigned)(n * a.Kpad + lchunk * 8) * 2u : OOB;      // rows >= Npad fall outside the descriptor: zeros
+            const int rho = blk_b[j] * 16 + lrow;                               // panel row; transposed product: channel order of tr_chan_of_row
+            const int n = bn * BN + (TRANSPOSED ? tr_chan_of_row(rho) : rho);
+            pw_[j] = live ? (unsigned)(n * 32 + lchunk * 8) * 2u : OOB;          // K-chunk major planes: [chunk][Npad][32]
         }
         ld_kc = 0; ld_c0 = 0; ld_ky = 0; ld_kx = 0;
     };
     // issue this wave's pieces of the next stage into ring slot `slot`, advance the cursor (to the next tile at the end of K)
     auto loader_issue = [&](int slot) __attribute__((always_inline)) {
         const unsigned tap_off = (unsigned)(ld_ky * a.Wi + ld_kx) * PS + (unsigned)ld_c0 * 2u;
-        const unsigned koff = (unsigned)ld_kc * (HBK * 2);
+        const unsigned koff = (unsigned)ld_kc * (unsigned)a.Npad * (HBK * 2);
         const unsigned sbase = lds0 + (unsigned)slot * STAGE;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
@@ -187,14 +191,16 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         // is a vmcnt that also covers every DMA piece issued before it; at the start of a tile that only waits for stages
         // this tile needs next, inside the epilogue it would drain the ring that is prefetching the next tile
         float ebias[TN], einv[TN];
+        if constexpr (!TRANSPOSED) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = bn * BN + wn * WN + j * 16 + lr;
-            ebias[j] = n < a.Cout ? a.bias[n] : 0.f;
-            einv[j] = n < a.Cout ? a.inv_scale[n] : 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const int n = bn * BN + wn * WN + j * 16 + lr;
+                ebias[j] = n < a.Cout ? a.bias[n] : 0.f;
+                einv[j] = n < a.Cout ? a.inv_scale[n] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(ebias[j]), "+v"(einv[j]));
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(ebias[j]), "+v"(einv[j]));
 
 #pragma unroll 1
         for (int kc = 0; kc < nk; ++kc) {
@@ -220,20 +226,29 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    if constexpr (TRANSPOSED) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             slot = slot + 1 == STAGES ? 0 : slot + 1;
         }
         // epilogue: the slot just consumed is the only one the loader does not own (it is refilled after the next tile's
         // first barrier); the other STAGES-1 slots keep filling for the next tile meanwhile
-        {
+        if constexpr (TRANSPOSED) {
+            // straight from the accumulators: no LDS, no barrier — the waves drift apart here and re-align at the next step
+            conv_f16s3_epilogue_regs<BM, BN, WM, WN, NT, EPI == EPI_SPLIT_RES>(a, acc, nullptr, bm, bn, tid, wm, wn, lr, lh, M);
+        } else {
             const int done = slot == 0 ? STAGES - 1 : slot - 1;
             __builtin_amdgcn_s_barrier();                        // every wave has read its last fragments from that slot
             conv_f16s3_epilogue<BM, BN, WM, WN, NT, EPI, STAGE, 1, true>(a, acc, smem + done * STAGE, bm, bn, tid, wm, wn, lr, lh, M, 0, ebias, einv);
+            __builtin_amdgcn_s_barrier();                        // transpose reads done before the slot is handed back to the loader
         }
-        __builtin_amdgcn_s_barrier();                            // transpose reads done before the slot is handed back to the loader
     }
     ring_wait_vmcnt<0>();                                        // trailing (out-of-range) pieces: nothing may be in flight at exit
 }

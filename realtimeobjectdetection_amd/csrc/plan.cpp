@@ -698,8 +698,9 @@ int Plan::load_weights(const float* w, size_t n) {
                             const float vs = (float)((double)v * ps);                                                    // exact (power of two)
                             const uint16_t h = f32_to_f16_rn(vs);
                             const uint16_t l = f32_to_f16_rn(vs - f16_to_f32(h));
-                            // K order of the split kernels: k = ((c/32)*k*k + tap)*32 + c%32 (channel chunk outer, tap inner)
-                            const int64_t idx = (int64_t)o * pc.Kpad + ((c / 32) * k * k + (ky * k + kx)) * 32 + (c % 32);
+                            // K order of the split kernels: k = ((c/32)*k*k + tap)*32 + c%32 (channel chunk outer, tap inner);
+                            // planes are K-chunk major, [chunk][Npad][32]: the rows of one stage are contiguous
+                            const int64_t idx = ((int64_t)((c / 32) * k * k + (ky * k + kx)) * pc.Npad + o) * 32 + (c % 32);
                             wh[idx] = h; wl[idx] = l;
                         }
             }
@@ -748,7 +749,7 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
     const View in = view_of(l.in_layer);
     a.in = in.base; a.in_ldc = in.ldc; a.in_coff = in.coff;
     a.B = batch; a.Hi = L.hin; a.Wi = L.win; a.Cin = pc.cin_p;
-    a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad;
+    a.w = d_weights + pc.w_off; a.bias = d_weights + pc.b_off; a.K = pc.K; a.Kpad = pc.Kpad; a.Npad = pc.Npad;
     a.in_bytes = (unsigned)std::min<int64_t>((int64_t)batch * in.H * in.W * in.ldc * 4, 0xFFFFFFFFll);
     a.w_bytes = (unsigned)std::min<int64_t>((int64_t)pc.Npad * pc.Kpad * 2, 0xFFFFFFFFll);
     if (pc.split) {
@@ -781,7 +782,7 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
         a.pw_wl = reinterpret_cast<const _Float16*>(d_weights + gc.wl_off);
         a.pw_inv_scale = d_weights + gc.s_off; a.pw_bias = d_weights + gc.b_off;
         a.pw_out = o.base; a.pw_out_ldc = o.ldc; a.pw_out_coff = o.coff;
-        a.pw_cout = G.cout; a.pw_k = L.cout; a.pw_leaky = G.leaky ? 1 : 0;
+        a.pw_cout = G.cout; a.pw_k = L.cout; a.pw_leaky = G.leaky ? 1 : 0; a.pw_npad = gc.Npad;
     }
     return RTOD_OK;
 }
