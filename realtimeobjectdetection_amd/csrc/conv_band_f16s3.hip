@@ -70,7 +70,14 @@ __device__ unsigned long long g_band_stamps[STAMP_BLOCKS * STAMP_WAVES * (STAMP_
 #endif
 
 constexpr int BAND_MAX_W = 94;
-constexpr int BAND_EPI_BYTES = 65536;          // the launch allocates at least this much LDS: the epilogue's transpose tile
+// Epilogue flavour.  0 (default): pixel-major accumulators, LDS-transposed stores (256-byte runs per pixel).  1: transposed
+// product + register epilogue (conv_f16s3_epilogue_regs; 64-byte segments per pixel, no LDS pass) — bit-identical, measured
+// 0.6-3 % slower on the band layers (A/B on one box, gpurun_out/ab1), so it is a build-time experiment only.
+#ifndef RTOD_BAND_TR
+#define RTOD_BAND_TR 0
+#endif
+constexpr bool BAND_TR = RTOD_BAND_TR != 0;
+constexpr int BAND_EPI_BYTES = BAND_TR ? 0 : 65536;      // LDS-transposed epilogue: the launch allocates at least the transpose tile
 __host__ __device__ constexpr int band_rows(int bm, int w) { return (bm + 2 * w + 2 + 15) / 16 * 16; }   // zero row follows
 
 // BM x BN workgroup tile, NWM x NWN waves of (BM/NWM) x (BN/NWN); MINW = waves/SIMD the register budget must allow.
@@ -137,7 +144,8 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     unsigned wbase[B_SLOTS];
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i)
-        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + row0 + i * RPP) * a.Kpad + c16 * 8) * 2u : OOB;
+        wbase[i] = (row0 + i * RPP < BN) ? (unsigned)((bn * BN + (BAND_TR ? tr_chan_of_row(row0 + i * RPP) : row0 + i * RPP)) * 32 + c16 * 8) * 2u : OOB;
+    const unsigned wchunk = (unsigned)a.Npad * (HBK * 2);        // bytes of one (chunk, tap) panel of a weight plane ([chunk][Npad][32])
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
@@ -178,7 +186,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     int ld_step = 0, ld_cc = 0, ld_tap = 0;                    // B chunk to be loaded next: local step, its chunk and tap
     auto gload_b = [&](BStage& S) {
         const bool live = ld_step < nsteps;
-        const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * (HBK * 2);
+        const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * wchunk;
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const unsigned wo = live ? wbase[i] : OOB;
@@ -272,9 +280,15 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                if constexpr (BAND_TR) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
             }
     };
 
@@ -339,7 +353,8 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #ifdef RTOD_DIAG
     if (a.dbg & 4) return;
 #endif
-    conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+    if constexpr (BAND_TR) conv_f16s3_epilogue_regs<BM, BN, WM, WN, NT, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M, kg);
+    else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {

@@ -55,6 +55,7 @@ struct ConvArgs {
     const float* w = nullptr;                   // packed [Npad][Kpad], k = (ky*kw+kx)*Cin + c
     const float* bias = nullptr;                // [Npad]
     int K = 0, Kpad = 0;
+    int Npad = 0;                               // split path: rows of one K-chunk panel of the weight planes ([Kpad/32][Npad][32] f16)
     int kh = 1, kw = 1, stride = 1, pad = 0;
     int Ho = 0, Wo = 0, Cout = 0;
     float* out = nullptr;       int64_t out_ldc = 0; int out_coff = 0;
@@ -62,6 +63,9 @@ struct ConvArgs {
     int leaky = 0;
     DecodeArgs dec;
     // split-precision path (conv_igemm_f16s3): pre-split, pre-scaled f16 weight planes [Npad][Kpad]
+    // Weight planes are K-chunk major: [Kpad/32 chunks][Npad rows][32 halves], chunk kc = (c/32)*kh*kw + tap.  One (chunk, tap)
+    // stage of a tile is then BN consecutive 64-byte rows: contiguous, full 128-byte lines (row-major [Npad][Kpad] planes made every
+    // stage BN separate 64-byte pieces at a stride of Kpad*2 bytes: half-line requests, twice the address traffic for the same bytes)
     const _Float16* w_hi = nullptr;
     const _Float16* w_lo = nullptr;
     const float* inv_scale = nullptr;           // [Npad]: 1 / (2^e_n * SPLIT_SCALE)
@@ -77,6 +81,7 @@ struct ConvArgs {
     const float* pw_inv_scale = nullptr;
     const float* pw_bias = nullptr;
     float* pw_out = nullptr;    int64_t pw_out_ldc = 0; int pw_out_coff = 0;
+    int pw_npad = 0;                            // Npad of the hosted 1x1 conv's weight planes
     int pw_cout = 0, pw_k = 0, pw_leaky = 0;    // pw_k = Cout of this conv = Kpad of the 1x1 (32 or 64); pw_cout 16, 32 or 64
 };
 
