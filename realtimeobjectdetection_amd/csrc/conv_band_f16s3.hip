@@ -353,8 +353,12 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #ifdef RTOD_DIAG
     if (a.dbg & 4) return;
 #endif
-    if constexpr (BAND_TR) conv_f16s3_epilogue_regs<BM, BN, WM, WN, NT, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, bm, bn, tid, wm, wn, lr, lh, M, kg);
-    else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+    if constexpr (BAND_TR) {
+        int mrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int m = bm * BM + wm * WM + i * 16 + lr; mrow[i] = m < M ? m : -1; }
+        conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, mrow, bn * BN + wn * WN, tid, lh, kg);
+    } else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {

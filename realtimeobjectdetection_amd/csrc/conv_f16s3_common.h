@@ -62,11 +62,13 @@ __host__ __device__ __forceinline__ int tr_chan_of_row(int rho) {
 }
 
 // Register epilogue of the transposed product.  acc[i][j]: pixel tile i (16 pixels), channel tile j of the wave.
+// mrow[i] = linear output pixel (b*Ho + y)*Wo + x of this lane's column in pixel tile i, or -1 if it lies outside the tensor;
+// cbase = first output channel of the wave's channel tiles.
 // KG == 2 (in-workgroup split-K): group 1 parks its accumulators in LDS (`smem`, 16 bytes per lane and tile: the MFMA layout
 // as it stands), one barrier, group 0 adds them to its own and stores.
-template <int BM, int BN, int WM, int WN, int NTG, bool RES, int KG = 1>
+template <int WM, int WN, bool RES, int KG = 1>
 __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem,
-                                                         int bm, int bn, int tidg, int wm, int wn, int lr, int lh, int M, int kg = 0) {
+                                                         const int (&mrow)[WM / 16], int cbase, int tidg, int lh, int kg = 0) {
     constexpr int TM = WM / 16, TN = WN / 16, NP = TN / 2;
     static_assert(TN % 2 == 0, "channel tiles come in pairs");
     if constexpr (KG == 2) {
@@ -94,7 +96,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x
     const _Float16* const rh = reinterpret_cast<const _Float16*>(a.res) + a.res_coff;
 #pragma unroll
     for (int P = 0; P < NP; ++P) {
-        const int c0 = bn * BN + wn * WN + 32 * P + 8 * lh;
+        const int c0 = cbase + 32 * P + 8 * lh;
         const bool cok = c0 < a.Cout;                                        // Cout % 8 == 0 for every split-format tensor
         const int cc = cok ? c0 : 0;
         // residual operands of this channel group first: their latency runs under the scale / bias loads and the conversions
@@ -102,8 +104,8 @@ __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x
         if constexpr (RES) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = bm * BM + wm * WM + i * 16 + lr;
-                const bool ok = m < M && cok;
+                const int m = mrow[i];
+                const bool ok = m >= 0 && cok;
                 const _Float16* q = rh + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + cc;
                 rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -113,7 +115,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x
         f32x4 bs0 = *reinterpret_cast<const f32x4*>(a.bias + cc), bs1 = *reinterpret_cast<const f32x4*>(a.bias + cc + 4);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = bm * BM + wm * WM + i * 16 + lr;
+            const int m = mrow[i];
             f16x8 ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -126,7 +128,7 @@ __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x
                 split_f16(v, h, l, amax);
                 ph[e] = h; pl[e] = l;
             }
-            if (m < M && cok) {
+            if (m >= 0 && cok) {
                 _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c0;
                 store_act16(q, ph, false);
                 store_act16(q + a.out_ldc, pl, false);

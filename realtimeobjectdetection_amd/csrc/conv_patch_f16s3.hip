@@ -1,0 +1,294 @@
+// 3x3 / pad 1 convolution over 2-D output tiles with an LDS-resident input patch (split-precision f16 MFMA), gfx950.
+//
+// Same contract, formats, K order and arithmetic as conv_igemm_f16s3.hip / conv_ring_f16s3.hip (reference: conv -> BN(eval)
+// -> leaky, src/darknet.py:467-501; shortcut 263-268) — bit-identical results — for the 3x3 layers whose images are too wide
+// for the band kernel (conv_band_f16s3.hip stages BM + 2W + 2 input pixels per tile: 5.8x the tile at W = 304).  On the
+// per-tap gathering kernels those layers re-read every input pixel once per tap from L2 (9 x 95 MB for YOLOv3's layer 3 at
+// 608x608 batch 8, 9 x 47 MB for layers 7 / 10: as much time as the layer's whole HBM traffic) and are bound by exactly that.
+//
+// A workgroup owns an 8 x 16 block of output pixels of one image and BN output channels.  Per 32-channel chunk it holds the
+// 10 x 18 input pixels that block can touch (1.4x the tile; out-of-image pixels are zeros IN the patch, so no per-tap
+// validity logic exists) in LDS; the A fragment of output row ty for tap (ky, kx) is patch rows (ty + ky) * 18 + kx + 0..15:
+// a constant shift per tap, like the band kernel's.  Patches are double-buffered and arrive by LDS-DMA one chunk ahead;
+// weights stream through an LDS-DMA ring of (chunk, tap) stages; the workgroup is persistent and both streams run across
+// tile boundaries (conv_ring_f16s3.hip's scheme), the epilogue works straight from the accumulators (transposed product,
+// conv_f16s3_common.h) with no barrier, so tile t+1's loads and first steps overlap tile t's stores.
+#include "conv_f16s3_common.h"
+#include <atomic>
+#include <cstdio>
+
+namespace rtod {
+
+template <int N> __device__ __forceinline__ void patch_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 20, "vmcnt literal");
+#define RTOD_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RTOD_VMCNT_CASE(1) RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(3) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(5) RTOD_VMCNT_CASE(6)
+    RTOD_VMCNT_CASE(7) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(9) RTOD_VMCNT_CASE(10) RTOD_VMCNT_CASE(11) RTOD_VMCNT_CASE(12)
+    RTOD_VMCNT_CASE(13) RTOD_VMCNT_CASE(14) RTOD_VMCNT_CASE(15) RTOD_VMCNT_CASE(16) RTOD_VMCNT_CASE(17) RTOD_VMCNT_CASE(18)
+    RTOD_VMCNT_CASE(19) RTOD_VMCNT_CASE(20)
+#undef RTOD_VMCNT_CASE
+}
+
+// two LDS-DMA pieces with one per-lane source offset (conv_ring_f16s3.hip: dma_pair)
+__device__ __forceinline__ void patch_dma_pair(const __amdgpu_buffer_rsrc_t rsrc_hi, const __amdgpu_buffer_rsrc_t rsrc_lo, unsigned voffset,
+                                               unsigned soff_hi, unsigned soff_lo, unsigned lds_hi, unsigned lds_lo) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %5 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc_hi), "s"(rsrc_lo), "s"(soff_hi), "s"(soff_lo), "s"(lds_hi), "s"(lds_lo)
+        : "memory");
+}
+
+constexpr int PT_TH = 8, PT_TW = 16, PT_BM = PT_TH * PT_TW;            // output tile: 8 rows x 16 columns
+constexpr int PT_PR = PT_TH + 2, PT_PC = PT_TW + 2, PT_PE = PT_PR * PT_PC;   // stride-1 patch: 10 x 18 = 180 input pixels
+constexpr int PT_PROWS = (PT_PE + 15) / 16 * 16;                        // LDS rows per plane (192: the tail rows hold zeros)
+constexpr int PT_PLANE = PT_PROWS * 64;                                 // bytes of one plane of one patch
+
+// LDS: [2 patch buffers][hi plane | lo plane][192 rows x 64 B], then [STAGES][hi BN x 64 B | lo BN x 64 B] weight stages.
+template <int BN, int NWM, int NWN, int STAGES, int MINW, int EPI>
+__global__ __launch_bounds__(NWM * NWN * 64, MINW)
+void conv_patch_f16s3_kernel(const ConvArgs a, const int tiles_x, const int tiles_y, const int grid_n) {
+    constexpr int BM = PT_BM, WM = BM / NWM, WN = BN / NWN, NW = NWM * NWN;
+    static_assert(WM % 16 == 0 && WN % 32 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile (channel tiles come in pairs)");
+    static_assert(EPI == EPI_SPLIT || EPI == EPI_SPLIT_RES, "patch kernel epilogues");
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int PANEL_B = BN * 64, BST = 2 * PANEL_B, PATCH = 2 * PT_PLANE;
+    constexpr int NPIECE = PT_PROWS / 16, PPW = (NPIECE + NW - 1) / NW;     // patch pieces (16 rows) and pieces per wave
+    constexpr int RB_B = BN / 16, B_PER = (RB_B + NW - 1) / NW;
+    constexpr int LB = 2 * B_PER, LP = 2 * PPW;                             // DMA instructions per wave: one weight stage, one patch
+    static_assert(STAGES >= 3 && STAGES - 1 < 9 && (STAGES - 2) * LB + LP <= 20, "ring depth / vmcnt literals");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wst = smem + 2 * PATCH;                 // weight stage ring
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n_tiles = a.B * tiles_y * tiles_x * grid_n;
+    const unsigned PS = (unsigned)a.in_ldc * 4u, lo_plane = (unsigned)a.in_ldc * 2u;
+    const int ncc = a.Cin / 32;
+    const unsigned wchunk = (unsigned)a.Npad * (HBK * 2);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // tile index -> (image, tile row, tile column, channel tile); XCD-aware remap as in conv_ring_f16s3.hip
+    auto tile_of = [&](int t, int& b, int& y0, int& x0, int& bn) __attribute__((always_inline)) {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = t & 7;
+        int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+        bn = u % grid_n; u /= grid_n;
+        x0 = (u % tiles_x) * PT_TW; u /= tiles_x;
+        y0 = (u % tiles_y) * PT_TH; b = u / tiles_y;
+    };
+
+    // ---- loader state.  Patch piece j of this wave: 16 patch rows; lane l -> patch row q = 16*piece + l/4 = (py, px),
+    // 16-byte position l&3 holding source chunk (l&3) ^ swizzle(q).  (py, px) do not depend on the tile.
+    const int lrow = lane >> 2;
+    int pc_piece[PPW], pdy[PPW], pdx[PPW]; unsigned pchunk[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        pc_piece[j] = (wave + j * NW) % NPIECE;
+        const int q = pc_piece[j] * 16 + lrow;
+        const int py = q / PT_PC, px = q - py * PT_PC;
+        pdy[j] = q < PT_PE ? py - 1 : -(1 << 20);               // pad 1; rows beyond the patch: always out of the image -> zeros
+        pdx[j] = px - 1;
+        pchunk[j] = (unsigned)(((lane & 3) ^ ((q >> 1) & 3)) * 8) * 2u;
+    }
+    int blk_b[B_PER]; unsigned wrow[B_PER];
+    const int lchunk = (lane & 3) ^ ((lrow >> 1) & 3);
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) blk_b[j] = (wave + j * NW) % RB_B;
+
+    int ld_tile = blockIdx.x;                                    // tile / chunk / tap the WEIGHT loader is at
+    int ld_cc = 0, ld_tap = 0;
+    int ld_bn = 0;
+    auto wload_enter_tile = [&]() __attribute__((always_inline)) {
+        int b, y0, x0;
+        tile_of(ld_tile < n_tiles ? ld_tile : 0, b, y0, x0, ld_bn);
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int rho = blk_b[j] * 16 + lrow;
+            wrow[j] = ld_tile < n_tiles ? (unsigned)((ld_bn * BN + tr_chan_of_row(rho)) * 32 + lchunk * 8) * 2u : OOB;
+        }
+        ld_cc = 0; ld_tap = 0;
+    };
+    auto wload_issue = [&](int slot) __attribute__((always_inline)) {
+        const unsigned koff = (unsigned)(ld_cc * 9 + ld_tap) * wchunk;
+        const unsigned sbase = lds0 + 2u * PATCH + (unsigned)slot * BST;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const unsigned l = sbase + (unsigned)blk_b[j] * 1024u;
+            patch_dma_pair(rs_wh, rs_wl, wrow[j], koff, koff, l, l + PANEL_B);
+        }
+        if (++ld_tap == 9) { ld_tap = 0; if (++ld_cc == ncc) { ld_tile += gridDim.x; wload_enter_tile(); } }
+    };
+    // patch of (tile pt, chunk pcc) into patch buffer pbuf
+    auto patch_issue = [&](int pt, int pcc, int pbuf) __attribute__((always_inline)) {
+        int b, y0, x0, bn_;
+        tile_of(pt < n_tiles ? pt : 0, b, y0, x0, bn_);
+        const unsigned soff = (unsigned)pcc * 64u;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int iy = y0 + pdy[j], ix = x0 + pdx[j];        // stride 1: input pixel = output pixel + (ky - 1, kx - 1)
+            const bool ok = pt < n_tiles && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const unsigned vo = ok ? (unsigned)((b * a.Hi + iy) * a.Wi + ix) * PS + (unsigned)a.in_coff * 2u + pchunk[j] : OOB;
+            const unsigned l = lds0 + (unsigned)pbuf * PATCH + (unsigned)pc_piece[j] * 1024u;
+            patch_dma_pair(rs_a, rs_a, vo, soff, soff + lo_plane, l, l + PT_PLANE);
+        }
+    };
+
+    // ---- consumer state
+    const int wm = wave / NWN, wn = wave - wm * NWN;
+    const int lr = lane & 15, lh = lane >> 4;
+    const int b_row = (wn * WN + lr) * 64 + ((lh ^ ((lr >> 1) & 3)) << 4);
+    int a_base[TM];                                              // patch row of this lane's pixel for tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_base[i] = (wm * (WM / 16) + i) * PT_PC + lr;
+
+    // prologue: the first patch, then STAGES-1 weight stages
+    wload_enter_tile();
+    patch_issue(blockIdx.x, 0, 0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) wload_issue(s);
+    int slot = 0, pbuf = 0;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int tb, y0, x0, bn;
+        tile_of(tile, tb, y0, x0, bn);
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll 1
+        for (int cc = 0; cc < ncc; ++cc) {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // this wave's pieces of the current weight stage (and, being older, of the current patch) have landed; younger:
+                // STAGES-2 weight stages and, for the STAGES-1 steps after a patch prefetch was issued, that patch
+                if (tap >= 1 && tap <= STAGES - 1) patch_wait_vmcnt<(STAGES - 2) * LB + LP>();
+                else patch_wait_vmcnt<(STAGES - 2) * LB>();
+                __builtin_amdgcn_s_barrier();                    // ... and everybody's; the previous step's slot / the other patch buffer are free
+                wload_issue(slot == 0 ? STAGES - 1 : slot - 1);  // the weight stage STAGES-1 steps ahead
+                if (tap == 0) {                                  // next chunk's patch (of the next tile after the last chunk) into the other buffer
+                    const bool last = cc + 1 == ncc;
+                    patch_issue(last ? tile + (int)gridDim.x : tile, last ? 0 : cc + 1, pbuf ^ 1);
+                }
+                const unsigned char* pp = smem + pbuf * PATCH;
+                const unsigned char* st = wst + slot * BST + b_row;
+                const int shift = (tap / 3) * PT_PC + (tap % 3);
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int q = a_base[i] + shift;
+                    const int o = q * 64 + ((lh ^ ((q >> 1) & 3)) << 4);
+                    ah[i] = *reinterpret_cast<const f16x8*>(pp + o);
+                    al[i] = *reinterpret_cast<const f16x8*>(pp + PT_PLANE + o);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
+                    bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+                slot = slot + 1 == STAGES ? 0 : slot + 1;
+            }
+            pbuf ^= 1;
+        }
+        // epilogue straight from the accumulators: pixel tile i is output row y0 + wm*(WM/16) + i, this lane's column x0 + lr
+        int mrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int oy = y0 + wm * (WM / 16) + i, ox = x0 + lr;
+            mrow[i] = (oy < a.Ho && ox < a.Wo) ? (tb * a.Ho + oy) * a.Wo + ox : -1;
+        }
+        conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES>(a, acc, nullptr, mrow, bn * BN + wn * WN, tid, lh);
+    }
+    patch_wait_vmcnt<0>();                                       // trailing (out-of-range) pieces: nothing may be in flight at exit
+}
+
+bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout) {
+    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && cout % 8 == 0;
+}
+
+// One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
+//   X(mode, BN, waves along M, waves along N, STAGES, MINW)
+#define RTOD_PATCH_TILES(X) X(0, 64, 4, 2, 4, 4) X(1, 128, 4, 2, 3, 2) X(2, 64, 4, 2, 3, 4) X(3, 128, 4, 2, 4, 2)
+
+#define RTOD_X_INFO(mode, bn, nwm, nwn, st, minw) {PT_BM, bn, "conv_patch_f16s3<8x16x" #bn "," #nwm "x" #nwn ",s" #st ">"},
+static const ConvVariantInfo kPatchModes[PATCH_MODES] = { RTOD_PATCH_TILES(RTOD_X_INFO) };
+#undef RTOD_X_INFO
+const ConvVariantInfo& conv_patch_mode_info(int mode) { return kPatchModes[mode < 0 || mode >= PATCH_MODES ? 0 : mode]; }
+
+int conv_patch_kernel_name(int mode, int epi, char* buf, size_t len) {
+#define RTOD_X_NAME(m, bn, nwm, nwn, st, minw) \
+    if (mode == m) return snprintf(buf, len, "void rtod::conv_patch_f16s3_kernel<" #bn ", " #nwm ", " #nwn ", " #st ", " #minw ", %d>(rtod::ConvArgs, int, int, int)", epi);
+    RTOD_PATCH_TILES(RTOD_X_NAME)
+#undef RTOD_X_NAME
+    return -1;
+}
+
+template <int BN, int NWM, int NWN, int STAGES, int MINW>
+static int launch_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int NT = NWM * NWN * 64;
+    const int tiles_x = (a.Wo + PT_TW - 1) / PT_TW, tiles_y = (a.Ho + PT_TH - 1) / PT_TH, gn = (a.Cout + BN - 1) / BN;
+    const int lds = 4 * PT_PLANE + STAGES * 2 * BN * 64;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return hip_fail(hipGetLastError(), "conv_patch_f16s3 device query");
+    const int by_lds = (160 * 1024) / lds, by_waves = (MINW * 4) / (NWM * NWN) > 0 ? (MINW * 4) / (NWM * NWN) : 1;
+    const int per_cu = by_lds < by_waves ? by_lds : by_waves;
+    const int64_t tiles = (int64_t)a.B * tiles_x * tiles_y * gn;
+    const int slots = cus * (per_cu > 0 ? per_cu : 1);
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    auto k_res = conv_patch_f16s3_kernel<BN, NWM, NWN, STAGES, MINW, EPI_SPLIT_RES>;
+    auto k_plain = conv_patch_f16s3_kernel<BN, NWM, NWN, STAGES, MINW, EPI_SPLIT>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return hip_fail(hipGetLastError(), "conv_patch_f16s3 LDS attribute");
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    if (a.res) hipLaunchKernelGGL(k_res, dim3(grid), dim3(NT), lds, s, a, tiles_x, tiles_y, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(grid), dim3(NT), lds, s, a, tiles_x, tiles_y, gn);
+    return hip_fail(hipGetLastError(), "conv_patch_f16s3 launch");
+}
+
+int launch_conv_patch_f16s3(const ConvArgs& a, int mode, hipStream_t s) {
+    if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_patch: null pointer"); return RTOD_E_ARG; }
+    if (!conv_patch_supported(a.kh, a.stride, a.pad, a.Cin, a.Cout) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled || a.pw_wh) {
+        set_error("launch_conv_patch: unsupported layer (k=%d s=%d pad=%d Cin=%d)", a.kh, a.stride, a.pad, a.Cin); return RTOD_E_ARG;
+    }
+    if (a.in_ldc % 8 || a.in_coff % 8 || a.out_ldc % 8 || a.out_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin) { set_error("launch_conv_patch: bad view / K"); return RTOD_E_ARG; }
+    if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_patch: buffer extents"); return RTOD_E_ARG; }
+    if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_patch: input view exceeds its buffer"); return RTOD_E_ARG; }
+    switch (mode) {
+#define RTOD_X_CASE(m, bn, nwm, nwn, st, minw) case m: return launch_patch<bn, nwm, nwn, st, minw>(a, s);
+        RTOD_PATCH_TILES(RTOD_X_CASE)
+#undef RTOD_X_CASE
+    }
+    set_error("launch_conv_patch: mode %d unsupported", mode);
+    return RTOD_E_ARG;
+}
+
+}  // namespace rtod

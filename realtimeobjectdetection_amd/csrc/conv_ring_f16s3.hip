@@ -242,7 +242,10 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         // first barrier); the other STAGES-1 slots keep filling for the next tile meanwhile
         if constexpr (TRANSPOSED) {
             // straight from the accumulators: no LDS, no barrier — the waves drift apart here and re-align at the next step
-            conv_f16s3_epilogue_regs<BM, BN, WM, WN, NT, EPI == EPI_SPLIT_RES>(a, acc, nullptr, bm, bn, tid, wm, wn, lr, lh, M);
+            int mrow[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { const int m = bm * BM + wm * WM + i * 16 + lr; mrow[i] = m < M ? m : -1; }
+            conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES>(a, acc, nullptr, mrow, bn * BN + wn * WN, tid, lh);
         } else {
             const int done = slot == 0 ? STAGES - 1 : slot - 1;
             __builtin_amdgcn_s_barrier();                        // every wave has read its last fragments from that slot

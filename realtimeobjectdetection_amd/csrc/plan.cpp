@@ -283,6 +283,7 @@ int Plan::set_option(const char* name, int value) {
     bool* flag = nullptr; int* num = nullptr;
     if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
     else if (k == "ring_kernel") flag = &opt_ring_kernel;
+    else if (k == "patch_kernel") flag = &opt_patch_kernel;
     else if (k == "pw_kernel") flag = &opt_pw_kernel;
     else if (k == "stem_kernel") flag = &opt_stem_kernel;
     else if (k == "band_kernel") flag = &opt_band_kernel;
@@ -728,6 +729,10 @@ int Plan::choose_variant(const Layer& L, int batch) const {
 }
 
 int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
+    if (v >= PATCH_VARIANT_BASE) {
+        if (pc.band || pc.pw) { set_error("patch variant requested for a band / pointwise layer"); return RTOD_E_STATE; }
+        return launch_conv_patch_f16s3(a, v - PATCH_VARIANT_BASE, s);
+    }
     if (v >= PW_VARIANT_BASE) {
         if (!pc.pw) { set_error("pointwise variant requested for a layer that is not a stand-alone 1x1 conv"); return RTOD_E_STATE; }
         return launch_conv_pw_f16s3(a, v - PW_VARIANT_BASE, s);
@@ -826,6 +831,11 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
             if (pw && vi.bn < L.cout) continue;                                       // fused pointwise: one N tile
             cand.push_back(v);
         }
+        if (!pw && opt_patch_kernel && conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && L.hout == L.hin && l.out_layer != -2)
+            for (int m = 0; m < PATCH_MODES; ++m) {
+                if (conv_patch_mode_info(m).bn > L.cout && conv_patch_mode_info(m).bn > 64) continue;
+                cand.push_back(PATCH_VARIANT_BASE + m);
+            }
         if (!pw && opt_ring_kernel)
             for (int m = 0; m < RING_MODES; ++m) {
                 const ConvVariantInfo& vi = conv_ring_mode_info(m);
@@ -901,6 +911,8 @@ int Plan::variant_for(const Launch& l, int batch) const {
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
         if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active())) return v;
+        if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 &&
+            conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin) return v;
         const int g = choose_variant_f16s3(layers[l.layer], batch);
         if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;
         return g;

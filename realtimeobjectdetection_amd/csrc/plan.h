@@ -89,6 +89,7 @@ struct Plan {
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
     bool opt_pw_kernel = false;       // streaming kernel for the stand-alone 1x1 layers it supports (measured slower than the LDS-tiled kernels on the
                                       // pixel-major activation layout: 64-byte half-line loads; kept as an option)
+    bool opt_patch_kernel = true;     // 2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers
     bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
     bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
     bool opt_fuse_decode = true;      // head decode in the head conv's epilogue (else stand-alone decode kernel)

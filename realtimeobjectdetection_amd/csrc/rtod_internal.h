@@ -135,6 +135,14 @@ constexpr int RING_VARIANT_BASE = 70;      // variant ids >= this: RING_VARIANT_
 const ConvVariantInfo& conv_ring_mode_info(int mode);
 int conv_ring_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s);
+// 2-D tiled 3x3 stride-1 kernel with an LDS-resident input patch (conv_patch_f16s3.hip): for images too wide for the band
+// kernel; bit-identical to the generic / ring tiles, so its modes are further autotune candidates of those layers.
+constexpr int PATCH_MODES = 4;
+constexpr int PATCH_VARIANT_BASE = 110;    // variant ids >= this: PATCH_VARIANT_BASE + mode
+bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout);
+const ConvVariantInfo& conv_patch_mode_info(int mode);
+int conv_patch_kernel_name(int mode, int epi, char* buf, size_t len);
+int launch_conv_patch_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 // Barrier-free streaming kernel for 1x1 convolutions (conv_pw_f16s3.hip): weights resident in LDS, activations straight
 // to registers.  A layer it supports always runs on it (its bits differ from the LDS-tiled kernels': swapped MFMA operands);
 // the modes (BN = 32 / 64 / 128 output channels per workgroup) agree bitwise.

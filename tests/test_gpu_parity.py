@@ -642,7 +642,7 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
     x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
     ref = None
-    for v in list(range(12)) + list(range(50, 59)) + list(range(70, 78)) + [90, 91, 92]:
+    for v in list(range(12)) + list(range(50, 59)) + list(range(70, 78)) + [90, 91, 92] + list(range(110, 114)):
         m = Darknet(cfg_path, True).eval()
         m.options["pw_kernel"] = 1                             # 90-92: slice widths of the optional streaming 1x1 kernel
         m.net_info["height"] = res
