@@ -239,6 +239,10 @@ void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w) {
     if (tid == 0) w.ndet[b] = base;
 }
 
+__global__ void nms_zero_kernel(int32_t* __restrict__ p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
 // ------------------------------------------------------------------------------------------ K3
 __global__ __launch_bounds__(256)
 void nms_emit_kernel(int B, int n, NmsWs w, float* __restrict__ out, int cap, int32_t* __restrict__ counts) {
@@ -275,7 +279,9 @@ int launch_write_results(const float* pred, int batch, int n, int num_class, flo
     if (ws_bytes < nms_workspace_bytes(batch, n)) { set_error("write_results: workspace too small"); return RTOD_E_ARG; }
     if (((uintptr_t)ws & 15) || ((uintptr_t)out & 15)) { set_error("write_results: workspace/out must be 16-byte aligned"); return RTOD_E_ARG; }
     NmsWs w = carve(ws, batch, n);
-    RTOD_HIP(hipMemsetAsync(w.cand, 0, sizeof(int32_t) * (3 * (size_t)batch + 4), s));
+    // counters zeroed by a kernel, not hipMemsetAsync: captured into a HIP graph the 28-byte memset node left the counters
+    // of the previous replay in place on ROCm 7.2 (second replay: candidates appended past the buffers, GPU fault)
+    hipLaunchKernelGGL(nms_zero_kernel, dim3(1), dim3(64), 0, s, w.cand, 3 * batch + 4);
     const int waves = batch * ((n + 63) / 64);
     hipLaunchKernelGGL(nms_filter_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, pred, batch, n, num_class, conf, w);
     hipLaunchKernelGGL(nms_sort_suppress_kernel, dim3(batch), dim3(NMS_BLOCK), 0, s, n, nms, w);

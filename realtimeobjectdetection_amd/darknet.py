@@ -371,6 +371,42 @@ class Darknet(nn.Module):
         if self.overflowed():
             raise FloatingPointError(_OVERFLOW_MSG)
 
+    def make_graphed(self, example_x, post=None):
+        """Capture ``forward`` (and optionally ``post(y)``, e.g. ``util.write_results_async``) for ``example_x``'s shape into a
+        HIP graph and return ``run(x) -> (y, post result)``.  ``rtod_forward`` only enqueues, so the whole launch list replays
+        as one graph launch: for small batches (YOLOv3-tiny batch 1: 24 launches of a few microseconds each) the per-launch
+        host cost is what limits the latency.  ``run`` copies ``x`` into a static input buffer and returns the static output
+        tensors: consume or clone them before the next call.  The range flag of split-f16 plans is not read (use
+        ``overflowed()``)."""
+        self._check_input(example_x)
+        dev = example_x.device
+        static_x = example_x.clone()
+        keep = self.overflow_check
+        self.overflow_check = "off"
+        try:
+            with torch.no_grad():
+                y = self.forward(static_x)                                # builds the plan, autotunes this batch size
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                             # warm-up on a non-default stream, as capture requires
+                    y = self.forward(static_x)
+                    r = post(y) if post is not None else None
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    y = self.forward(static_x)
+                    r = post(y) if post is not None else None
+        finally:
+            self.overflow_check = keep
+
+        def run(x):
+            static_x.copy_(x, non_blocking=True)
+            graph.replay()
+            return y, r
+        run.graph = graph
+        return run
+
     def forward_timed(self, x):
         """Forward with a HIP-event pair around every launch; returns (out, ms per launch)."""
         self._check_input(x)

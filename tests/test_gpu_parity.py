@@ -659,3 +659,22 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
         else:
             assert torch.equal(y, ref), v
         del m
+
+
+def test_make_graphed_replays_forward_and_write_results(tmp_path_factory):
+    """Darknet.make_graphed: forward + write_results_async captured once, replayed on new inputs, equals the eager results."""
+    from realtimeobjectdetection_amd.util import write_results_async
+    m, _ = gpu_model("yolov3-tiny", 416, tmp_path_factory)
+    xs = [torch.from_numpy(synth.synth_frames(1, 416, seed=synth.FRAME_SEED + i)).cuda() for i in range(3)]
+    with torch.no_grad():
+        want = []
+        for x in xs:
+            y = m(x)
+            r, c = write_results_async(y, 80, 0.6, 0.5, cap=2048)
+            want.append((y.clone(), r.clone(), c.clone()))
+    run = m.make_graphed(xs[0], post=lambda y: write_results_async(y, 80, 0.6, 0.5, cap=2048))
+    for x, (wy, wr, wc) in zip(xs, want):
+        y, (r, c) = run(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y, wy) and torch.equal(c, wc)
+        assert torch.equal(r[:int(c[0])], wr[:int(wc[0])])

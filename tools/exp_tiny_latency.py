@@ -18,6 +18,7 @@ with tempfile.TemporaryDirectory() as d:
     m.net_info["height"] = args.res
     m.load_weights(synth.write_weights_file(os.path.join(d, "t.weights"), synth.synth_weights(ir)))
 x = torch.from_numpy(synth.synth_frames(args.batch, args.res)).cuda()
+print('stage: eager', flush=True)
 with torch.no_grad():
     for _ in range(20):
         write_results_async(m(x), 80, 0.6, 0.5, cap=4096)
@@ -28,5 +29,25 @@ with torch.no_grad():
         write_results_async(m(x), 80, 0.6, 0.5, cap=4096)
     e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
+print('stage: graph', flush=True)
+# the same work replayed as one HIP graph (Darknet.make_graphed): forward + write_results_async
+run = m.make_graphed(x, post=lambda y: write_results_async(y, 80, 0.6, 0.5, cap=4096))
+for _ in range(20):
+    run(x)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(args.iters):
+    run(x)
+e1.record(); torch.cuda.synchronize()
+ms_graph = e0.elapsed_time(e1) / args.iters
+print('stage: readback', flush=True)
+import time
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    y, (rows, counts) = run(x)
+    n = int(counts[0].item())                      # one result on the host per frame: the serving latency
+lat = (time.perf_counter() - t0) / args.iters * 1e3
+print({"graph_ms_per_batch": round(ms_graph, 4), "graph_frames_per_s": round(args.batch * 1000.0 / ms_graph, 1),
+       "graph_latency_with_host_readback_ms": round(lat, 4), "launches": m._info.n_launches})
 print({"net": "yolov3-tiny", "res": args.res, "batch": args.batch, "precision": m.active_precision, "ms_per_batch": round(ms, 4),
        "frames_per_s": round(args.batch * 1000.0 / ms, 1), "gflop_per_frame": round(ir.conv_flops / 1e9, 3)})
