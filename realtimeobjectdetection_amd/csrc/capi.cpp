@@ -92,6 +92,7 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 }
 
 const char* rtod_conv_variant_name(int variant) {
+    if (variant == 100 + STEM2_VARIANT) return "conv_stem2_f16s3<8x16, stem + 3x3 s2 + 1x1>";
     if (variant >= 100 + PATCH_VARIANT_BASE && variant < 100 + PATCH_VARIANT_BASE + PATCH_MODES) return conv_patch_mode_info(variant - 100 - PATCH_VARIANT_BASE).name;
     if (variant >= 100 + PW_VARIANT_BASE && variant < 100 + PW_VARIANT_BASE + PW_MODES) return conv_pw_mode_info(variant - 100 - PW_VARIANT_BASE).name;
     if (variant >= 100 + RING_VARIANT_BASE && variant < 100 + RING_VARIANT_BASE + RING_MODES) return conv_ring_mode_info(variant - 100 - RING_VARIANT_BASE).name;
@@ -123,7 +124,8 @@ int rtod_plan_launch_kernel_name(const rtod_plan* plan, int index, char* buf, si
     if (li.kind != LK_CONV || li.flops_per_frame == 0) return RTOD_OK;                 // non-conv launch / conv hosted by the previous launch: empty name
     const int epi = li.fused_decode ? 2 : (li.fused_pointwise ? (li.fused_residual ? 4 : 3) : (li.fused_residual ? 1 : 0));
     int n = -1;
-    if (li.variant >= 100 + PW_VARIANT_BASE) n = conv_pw_kernel_name(li.variant - 100 - PW_VARIANT_BASE, li.cin, buf, len);
+    if (li.variant == 100 + STEM2_VARIANT) n = conv_stem2_kernel_name(li.fused_pointwise, buf, len);
+    else if (li.variant >= 100 + PW_VARIANT_BASE) n = conv_pw_kernel_name(li.variant - 100 - PW_VARIANT_BASE, li.cin, buf, len);
     else return rtod_conv_kernel_name(li.variant, epi, buf, len);
     if (n < 0 || (size_t)n >= len) { set_error("launch_kernel_name: buffer too small"); return RTOD_E_ARG; }
     return RTOD_OK;

@@ -1,0 +1,335 @@
+// Stem + first down-sampling convolution in one kernel (split-precision f16 MFMA), gfx950.
+//
+// Layers 0 and 1 of Darknet-53 (reference: conv -> BN(eval) -> leaky twice, src/darknet.py:467-501; cfg/yolov3.cfg blocks 1-2):
+//     s  = leaky(conv3x3 s1 p1 (x [B,3,H,W] fp32 NCHW) -> 32 channels)          608x608x32 at the benchmark size
+//     o1 = leaky(conv3x3 s2 p1 (s) -> 64 channels)                               304x304x64
+//     o2 = leaky(conv1x1 (o1) -> 32 channels)          (optional: the 1x1 conv the plan hosts in layer 1's epilogue)
+// Stand-alone, the stem writes s to HBM (378 MB at 608x608 batch 8) and layer 1 reads it back through a 9-tap gather:
+// 0.12 + 0.19 ms of a 4.2 ms forward for 3 % of its FLOPs.  Here s never leaves the CU.
+//
+// A persistent workgroup (8 waves, one per CU) walks 8 x 16 tiles of o1.  Per tile:
+//   1. stem phase: the 17 x 33 pixels of s the tile touches are computed 16 pixels at a time — the 27-tap dot product is
+//      one k32 step of v_mfma_f32_16x16x32_f16 in the split arithmetic of conv_stem.hip (x*8 = xh + xl, three products) —
+//      scaled / biased / activated / split exactly as conv_stem_split_kernel does, and written to an LDS patch in the
+//      activation format (hi plane, lo plane, 64-byte rows, chunk swizzle).  Pixels outside the image are written as zeros
+//      (layer 1's padding).  Columns are stored even-then-odd per patch row, so the stride-2 taps read 16 CONSECUTIVE rows;
+//   2. layer-1 phase: wave w owns output row w of the tile: 9 taps x (1 pixel tile x 4 channel tiles x 3 products), weights
+//      of all 9 taps resident in LDS for the lifetime of the workgroup (73 KB) — no staging, no barrier between taps;
+//   3. epilogue from the accumulators (transposed product, conv_f16s3_common.h): the lane's 8 consecutive channels of a pixel
+//      are stored as 16 bytes per plane AND are, as they stand, the activation operand of the hosted 1x1 conv (k = 8*lh + j
+//      of 32-channel chunk P), whose two k32 steps run on them directly.
+// Arithmetic, K order and rounding points are those of the stand-alone kernels (conv_stem.hip, conv_igemm_f16s3.hip with
+// EPI_SPLIT_PW): the outputs are bit-identical to the unfused plan's.
+#include "conv_f16s3_common.h"
+#include <atomic>
+#include <cstdio>
+
+namespace rtod {
+
+constexpr int S2_TH = 8, S2_TW = 16;                                   // o1 tile
+constexpr int S2_PR = 2 * S2_TH + 1, S2_PC = 2 * S2_TW + 1;            // 17 x 33 pixels of s
+constexpr int S2_EVEN = S2_TW + 1;                                     // even columns first (17), then the 16 odd ones
+constexpr int S2_PE = S2_PR * S2_PC;                                   // 561
+constexpr int S2_GROUPS = (S2_PE + 15) / 16;                           // 36 groups of 16 patch pixels
+constexpr int S2_PROWS = S2_GROUPS * 16, S2_PLANE = S2_PROWS * 64;     // 576 rows, 36 864 bytes per plane
+constexpr int S2_W1 = 9 * 64 * 64;                                     // one plane of layer 1's weights in LDS: [tap][64 rows][64 B]
+constexpr int S2_W2 = 2 * 32 * 64;                                     // one plane of the hosted 1x1 conv: [chunk][32 rows][64 B]
+constexpr int S2_WAVES = 8, S2_NT = S2_WAVES * 64;
+constexpr int S2_GPW = (S2_GROUPS + S2_WAVES - 1) / S2_WAVES;          // pixel groups per wave (5; the last wave slots are idle)
+constexpr int S2_LDS = 2 * S2_PLANE + 2 * S2_W1 + 2 * S2_W2 + (64 + 64 + 32 + 32) * 4;
+
+struct Stem2Args {
+    const float* x; unsigned x_bytes;                 // [B,3,H,W] fp32
+    const _Float16* w0h; const _Float16* w0l;         // stem weights [32][32] f16 hi / lo, k = (ky*3+kx)*3 + c (plan.cpp, stem split packing)
+    const float* inv0; const float* bias0; int leaky0;
+    ConvArgs c1;                                      // layer 1 (weights, scale, bias, output view) with the hosted 1x1 conv's pw_* fields
+    int B, H, W;                                      // input / stem geometry; c1.Ho, c1.Wo = layer 1's output
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void s2_dma_pair(const __amdgpu_buffer_rsrc_t rsrc_hi, const __amdgpu_buffer_rsrc_t rsrc_lo, unsigned voffset,
+                                            unsigned soff, unsigned lds_hi, unsigned lds_lo) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc_hi), "s"(rsrc_lo), "s"(soff), "s"(lds_hi), "s"(lds_lo)
+        : "memory");
+}
+
+template <bool PW>
+__global__ __launch_bounds__(S2_NT, 2)
+void conv_stem2_f16s3_kernel(const Stem2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const patch = smem;                                  // [hi | lo][576][64]
+    unsigned char* const w1 = smem + 2 * S2_PLANE;                      // [hi | lo][9][64][64]
+    unsigned char* const w2 = w1 + 2 * S2_W1;                           // [hi | lo][2][32][64]
+    float* const tab = reinterpret_cast<float*>(w2 + 2 * S2_W2);        // inv1*8 [64], bias1*8 [64], inv2*8 [32], bias2*8 [32]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lr = lane & 15, lh = lane >> 4;
+    const ConvArgs& c = a.c1;
+    const int H = a.H, W = a.W;
+    const int64_t plane = (int64_t)H * W;
+    const int n_tiles = a.B * a.tiles_y * a.tiles_x;
+
+    // ---- once per workgroup: layer 1's (and the hosted conv's) weights -> LDS, scale / bias tables
+    {
+        const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)c.w_hi, 0, c.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)c.w_lo, 0, c.w_bytes, 0x00020000);
+        const unsigned lds0 = (unsigned)(size_t)w1;
+        const int lrow = lane >> 2;
+        for (int p = wave; p < 9 * 4; p += S2_WAVES) {                  // (tap, 16-row block): one hi + one lo piece each
+            const int tap = p >> 2, rb = p & 3;
+            const int rho = rb * 16 + lrow;
+            const int ch = (lane & 3) ^ ((rho >> 1) & 3);
+            const unsigned vo = (unsigned)(tr_chan_of_row(rho) * 32 + ch * 8) * 2u;      // planes are [chunk*9 + tap][Npad][32], Cin = 32: chunk 0
+            const unsigned l = lds0 + (unsigned)(tap * 64 * 64 + rb * 1024);
+            s2_dma_pair(rs_wh, rs_wl, vo, (unsigned)tap * (unsigned)c.Npad * 64u, l, l + S2_W1);
+        }
+        if constexpr (PW) {
+            const unsigned pwb = (unsigned)c.pw_npad * (unsigned)c.pw_k * 2u;
+            const __amdgpu_buffer_rsrc_t rs_2h = __builtin_amdgcn_make_buffer_rsrc((void*)c.pw_wh, 0, pwb, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_2l = __builtin_amdgcn_make_buffer_rsrc((void*)c.pw_wl, 0, pwb, 0x00020000);
+            const unsigned lds2 = (unsigned)(size_t)w2;
+            for (int p = wave; p < 2 * 2; p += S2_WAVES) {              // (chunk, 16-row block)
+                const int kc = p >> 1, rb = p & 1;
+                const int rho = rb * 16 + lrow;
+                const int ch = (lane & 3) ^ ((rho >> 1) & 3);
+                const unsigned vo = (unsigned)(tr_chan_of_row(rho) * 32 + ch * 8) * 2u;
+                const unsigned l = lds2 + (unsigned)(kc * 32 * 64 + rb * 1024);
+                s2_dma_pair(rs_2h, rs_2l, vo, (unsigned)kc * (unsigned)c.pw_npad * 64u, l, l + S2_W2);
+            }
+        }
+        for (int i = tid; i < 64; i += S2_NT) { tab[i] = c.inv_scale[i] * SPLIT_SCALE; tab[64 + i] = c.bias[i] * SPLIT_SCALE; }
+        if constexpr (PW)
+            for (int i = tid; i < 32; i += S2_NT) { tab[128 + i] = c.pw_inv_scale[i] * SPLIT_SCALE; tab[160 + i] = c.pw_bias[i] * SPLIT_SCALE; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- stem constants of this lane: weight fragments (rows in the transposed product's channel order), scale, bias
+    f16x8 w0h[2], w0l[2];
+    float inv0[8], bias0[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = tr_chan_of_row(t * 16 + lr);
+        w0h[t] = *reinterpret_cast<const f16x8*>(a.w0h + n * 32 + lh * 8);
+        w0l[t] = *reinterpret_cast<const f16x8*>(a.w0l + n * 32 + lh * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { inv0[e] = a.inv0[8 * lh + e]; bias0[e] = a.bias0[8 * lh + e]; }
+    // tap geometry of this lane's 8 k values (k = 8*lh + e = (ky*3 + kx)*3 + c): element offset from the pixel's
+    // receptive-field corner and the neighbours it needs (conv_stem.hip)
+    int koff[8], need[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = lh * 8 + e;
+        const int tap = k / 3, cc = k - tap * 3;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        koff[e] = (cc * (int)plane + ky * W + kx) * 4;
+        need[e] = (ky == 0 ? 1 : 0) | (ky == 2 ? 2 : 0) | (kx == 0 ? 4 : 0) | (kx == 2 ? 8 : 0) | (k >= 27 ? 16 : 0) | 32;
+    }
+    // patch pixels of this lane's groups: group g = wave + j*8, patch row q = 16*g + lr = py*33 + column slot
+    int gpy[S2_GPW], gpx[S2_GPW], gq[S2_GPW];
+#pragma unroll
+    for (int j = 0; j < S2_GPW; ++j) {
+        const int g = wave + j * S2_WAVES;
+        const int q = g * 16 + lr;
+        const int py = q / S2_PC, cs = q - py * S2_PC;
+        gq[j] = q;
+        gpy[j] = (g < S2_GROUPS && q < S2_PE) ? py : -(1 << 20);      // beyond the patch: never in the image -> zeros
+        gpx[j] = cs < S2_EVEN ? 2 * cs : 2 * (cs - S2_EVEN) + 1;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const int w_lane = lr * 64 + ((lh ^ ((lr >> 1) & 3)) << 4);         // fragment address inside a 16-row weight block
+    float amax = 0.f;
+    _Float16* const o1 = reinterpret_cast<_Float16*>(c.out) + c.out_coff;
+    _Float16* const o2 = PW ? reinterpret_cast<_Float16*>(c.pw_out) + c.pw_out_coff : nullptr;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int u = tile;
+        const int x0 = (u % a.tiles_x) * S2_TW; u /= a.tiles_x;
+        const int y0 = (u % a.tiles_y) * S2_TH;
+        const int b = u / a.tiles_y;
+        const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;                   // stem pixel of patch (0, 0)
+
+        // ---- 1. stem phase
+#pragma unroll
+        for (int j = 0; j < S2_GPW; ++j) {
+            if (wave + j * S2_WAVES >= S2_GROUPS) break;                 // wave-uniform
+            const int sy = sy0 + gpy[j], sx = sx0 + gpx[j];
+            const bool inimg = (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            const int edge = (sy - 1 < 0 ? 1 : 0) | (sy + 1 >= H ? 2 : 0) | (sx - 1 < 0 ? 4 : 0) | (sx + 1 >= W ? 8 : 0) | 16 | (inimg ? 0 : 32);
+            const int base = (b * 3 * (int)plane + (sy - 1) * W + (sx - 1)) * 4;
+            f16x8 xh, xl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned vo = (need[e] & edge) ? 0x80000000u : (unsigned)(base + koff[e]);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, 0, 0)) * SPLIT_SCALE;
+                const _Float16 h = (_Float16)v;
+                xh[e] = h; xl[e] = (_Float16)(v - (float)h);
+            }
+            f16x8 ph, pl;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[t], xl, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0l[t], xh, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[t], xh, s, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = s[e] * inv0[4 * t + e] + bias0[4 * t + e];
+                    if (a.leaky0) v = v > 0.f ? v : v * 0.1f;
+                    v = inimg ? v * SPLIT_SCALE : 0.f;                   // outside the image: layer 1's zero padding
+                    _Float16 h, l;
+                    split_f16(v, h, l, amax);
+                    ph[4 * t + e] = h; pl[4 * t + e] = l;
+                }
+            }
+            const int q = gq[j];
+            const int o = q * 64 + ((lh ^ ((q >> 1) & 3)) << 4);
+            *reinterpret_cast<f16x8*>(patch + o) = ph;
+            *reinterpret_cast<f16x8*>(patch + S2_PLANE + o) = pl;
+        }
+        __syncthreads();
+
+        // ---- 2. layer 1: this wave's output row (ty = wave), 64 channels
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int q = (2 * wave + ky) * S2_PC + (kx == 1 ? S2_EVEN : (kx >> 1)) + lr;      // even / odd / next even column slot
+            const int o = q * 64 + ((lh ^ ((q >> 1) & 3)) << 4);
+            const f16x8 xh = *reinterpret_cast<const f16x8*>(patch + o);
+            const f16x8 xl = *reinterpret_cast<const f16x8*>(patch + S2_PLANE + o);
+            const unsigned char* wp = w1 + tap * 64 * 64 + w_lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + t * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + S2_W1 + t * 1024);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[t], 0, 0, 0);
+            }
+        }
+
+        // ---- 3. epilogue: pixel (y0 + wave, x0 + lr), channels 32P + 8*lh + {0..7}
+        const int oy = y0 + wave, ox = x0 + lr;
+        const bool pok = oy < c.Ho && ox < c.Wo;
+        const int64_t m = pok ? ((int64_t)b * c.Ho + oy) * c.Wo + ox : 0;
+        f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            const int c0 = 32 * P + 8 * lh;
+            const f32x4 i0 = *reinterpret_cast<const f32x4*>(tab + c0), i1 = *reinterpret_cast<const f32x4*>(tab + c0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(tab + 64 + c0), b1 = *reinterpret_cast<const f32x4*>(tab + 64 + c0 + 4);
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = e < 4 ? acc[2 * P][e] : acc[2 * P + 1][e - 4];
+                float v = s * (e < 4 ? i0[e] : i1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+                if (c.leaky) v = v > 0.f ? v : v * 0.1f;
+                _Float16 h, l;
+                split_f16(v, h, l, amax);
+                ph[e] = h; pl[e] = l;
+            }
+            if (pok) {
+                _Float16* q = o1 + m * 2 * c.out_ldc + c0;
+                store_act16(q, ph, false);
+                store_act16(q + c.out_ldc, pl, false);
+            }
+            if constexpr (PW) {                                          // the stored values are the 1x1 conv's operand of k chunk P
+                const unsigned char* wp = w2 + P * 32 * 64 + w_lane;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + t * 1024);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + S2_W2 + t * 1024);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, pl, acc2[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ph, acc2[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ph, acc2[t], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (PW) {
+            const int c0 = 8 * lh;
+            const f32x4 i0 = *reinterpret_cast<const f32x4*>(tab + 128 + c0), i1 = *reinterpret_cast<const f32x4*>(tab + 128 + c0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(tab + 160 + c0), b1 = *reinterpret_cast<const f32x4*>(tab + 160 + c0 + 4);
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = e < 4 ? acc2[0][e] : acc2[1][e - 4];
+                float v = s * (e < 4 ? i0[e] : i1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+                if (c.pw_leaky) v = v > 0.f ? v : v * 0.1f;
+                _Float16 h, l;
+                split_f16(v, h, l, amax);
+                ph[e] = h; pl[e] = l;
+            }
+            if (pok) {
+                _Float16* q = o2 + m * 2 * c.pw_out_ldc + c0;
+                store_act16(q, ph, false);
+                store_act16(q + c.pw_out_ldc, pl, false);
+            }
+        }
+        __syncthreads();                                                 // every wave is done with the patch before the next tile overwrites it
+    }
+    split_overflow_report(c.ovf, amax);
+}
+
+bool conv_stem2_supported(int k0, int s0, int p0, int cin0, int cout0, int k1, int s1, int p1, int cout1, int pw_cout) {
+    return k0 == 3 && s0 == 1 && p0 == 1 && cin0 == 3 && cout0 == 32 && k1 == 3 && s1 == 2 && p1 == 1 && cout1 == 64 &&
+           (pw_cout == 0 || pw_cout == 32);
+}
+
+int conv_stem2_kernel_name(int pw, char* buf, size_t len) {
+    return snprintf(buf, len, "void rtod::conv_stem2_f16s3_kernel<%s>(rtod::Stem2Args)", pw ? "true" : "false");
+}
+
+int launch_conv_stem2_f16s3(const float* x, int B, int H, int W, const _Float16* w0h, const _Float16* w0l, const float* inv0, const float* bias0,
+                            int leaky0, const ConvArgs& c1, hipStream_t s) {
+    if (!x || !w0h || !w0l || !inv0 || !bias0 || !c1.w_hi || !c1.w_lo || !c1.inv_scale || !c1.bias || !c1.out) { set_error("conv_stem2: null pointer"); return RTOD_E_ARG; }
+    const bool pw = c1.pw_wh != nullptr;
+    if (c1.Cin != 32 || c1.Cout != 64 || c1.kh != 3 || c1.kw != 3 || c1.stride != 2 || c1.pad != 1 || c1.Hi != H || c1.Wi != W ||
+        c1.Ho != (H - 1) / 2 + 1 || c1.Wo != (W - 1) / 2 + 1 || c1.res || c1.dec.enabled || c1.out_ldc % 8 || c1.out_coff % 8 || c1.Npad < 64) {
+        set_error("conv_stem2: layer 1 is not a 3x3 stride-2 32 -> 64 convolution over the stem's output"); return RTOD_E_ARG;
+    }
+    if (pw && (!c1.pw_wl || !c1.pw_inv_scale || !c1.pw_bias || !c1.pw_out || c1.pw_k != 64 || c1.pw_cout != 32 || c1.pw_npad < 32 || c1.pw_out_ldc % 8 || c1.pw_out_coff % 8)) {
+        set_error("conv_stem2: hosted 1x1 conv must be 64 -> 32"); return RTOD_E_ARG;
+    }
+    if ((int64_t)B * 3 * H * W * 4 >= (1ll << 31) || (int64_t)B * c1.Ho * c1.Wo >= (1ll << 31)) { set_error("conv_stem2: input exceeds 2 GiB / int32 pixels"); return RTOD_E_ARG; }
+    Stem2Args a;
+    a.x = x; a.x_bytes = (unsigned)((int64_t)B * 3 * H * W * 4);
+    a.w0h = w0h; a.w0l = w0l; a.inv0 = inv0; a.bias0 = bias0; a.leaky0 = leaky0;
+    a.c1 = c1; a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (c1.Wo + S2_TW - 1) / S2_TW; a.tiles_y = (c1.Ho + S2_TH - 1) / S2_TH;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return hip_fail(hipGetLastError(), "conv_stem2 device query");
+    const int64_t tiles = (int64_t)B * a.tiles_x * a.tiles_y;
+    const int grid = (int)(tiles < cus ? tiles : cus);
+    auto k_pw = conv_stem2_f16s3_kernel<true>;
+    auto k_plain = conv_stem2_f16s3_kernel<false>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return hip_fail(hipGetLastError(), "conv_stem2 LDS attribute");
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    static_assert(S2_LDS <= 160 * 1024, "LDS budget");
+    if (pw) hipLaunchKernelGGL(k_pw, dim3(grid), dim3(S2_NT), S2_LDS, s, a);
+    else hipLaunchKernelGGL(k_plain, dim3(grid), dim3(S2_NT), S2_LDS, s, a);
+    return hip_fail(hipGetLastError(), "conv_stem2 launch");
+}
+
+}  // namespace rtod

@@ -125,7 +125,7 @@ void nms_filter_kernel(const float* __restrict__ pred, int B, int n, int num_cla
                 const int slot = atomicAdd(&w.cand[b], 1);
                 const uint64_t key = ((uint64_t)bi << (32 + NMS_ROW_BITS)) |
                                      ((uint64_t)float_desc_key(obj) << NMS_ROW_BITS) | (uint64_t)r;
-                w.keys[(int64_t)b * w.P + slot] = key;
+                if (slot < w.P) w.keys[(int64_t)b * w.P + slot] = key;   // (always true with zeroed counters; never write past the image's slots)
             }
         }
     }
@@ -152,7 +152,7 @@ void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w) {
     __shared__ int s_nseg;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int cnt = w.cand[b];
+    const int cnt = min(w.cand[b], w.P);
     uint64_t* gk = w.keys + (int64_t)b * w.P;
     int* segs = w.segs + (int64_t)b * (NMS_MAX_CLASSES + 1);
     if (cnt == 0) { if (tid == 0) w.ndet[b] = 0; return; }

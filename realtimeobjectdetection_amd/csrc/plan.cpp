@@ -283,6 +283,7 @@ int Plan::set_option(const char* name, int value) {
     bool* flag = nullptr; int* num = nullptr;
     if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
     else if (k == "ring_kernel") flag = &opt_ring_kernel;
+    else if (k == "stem2_kernel") flag = &opt_stem2_kernel;
     else if (k == "patch_kernel") flag = &opt_patch_kernel;
     else if (k == "pw_kernel") flag = &opt_pw_kernel;
     else if (k == "stem_kernel") flag = &opt_stem_kernel;
@@ -452,6 +453,16 @@ int Plan::plan_buffers() {
         if (H.cout % 32 || H.cout > 64 || (G.cout != 16 && G.cout != 32 && G.cout != 64) || G.fused_into >= 0) continue;   // PW_MAX_K
         if (conv_band_supported(H.size, H.stride, H.pad, H.cin, H.win) && H.hout == H.hin) continue;   // band kernel: no pointwise epilogue
         h.pw_guest = (int)i + 1; g.pw_host = (int)i;
+    }
+    // stem + layer 1 fusion candidate: launch 0 is the stem kernel, launch 1 the conv of layer 1 reading only it, nothing else reads layer 0
+    stem2_pattern = false;
+    if (launches.size() >= 2 && launches[0].kind == LK_STEM && launches[1].kind == LK_CONV && launches[1].layer == 1 && launches[1].in_layer == 0 &&
+        launches[1].in2_layer < 0 && launches[1].out_layer == 1 && cons[0].size() == 1 && n > 1) {
+        const Layer& L0 = layers[0]; const Layer& L1 = layers[1];
+        int pwc = 0;
+        if (launches[1].pw_guest >= 0) pwc = layers[launches[launches[1].pw_guest].layer].cout;
+        stem2_pattern = L0.bn && L1.bn && conv_stem2_supported(L0.size, L0.stride, L0.pad, L0.cin, L0.cout, L1.size, L1.stride, L1.pad, L1.cout, pwc) &&
+                        (pwc == 0 || pwc == 32);
     }
     // liveness per buffer over launch time (= layer index of the launch)
     const int NB = (int)bufs.size();
@@ -928,6 +939,7 @@ int Plan::variant_for(const Launch& l, int batch) const {
 }
 
 bool Plan::pw_active() const { return precision == 1 && opt_fuse_pointwise; }
+bool Plan::stem2_active() const { return precision == 1 && opt_stem2_kernel && stem2_pattern && !keep_all && convs[launches[0].conv_slot].split; }
 
 int Plan::choose_variant_f16s3(const Layer& L, int batch) const {
     if (opt_force_f16s3_variant >= 0 && opt_force_f16s3_variant < HV_COUNT) return opt_force_f16s3_variant;
@@ -969,13 +981,20 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 rc = build_conv_args(l, batch, out, a);
                 if (rc) return rc;
                 if (!pc.split) rc = launch_conv(a, choose_variant(L, batch), s);
-                else {
-                    if (tune_now) { rc = tune_launch(li, a, batch, s); if (rc) return rc; }
+                else if (li == 1 && stem2_active()) {                  // stem + this conv (+ its hosted 1x1) in one kernel
+                    const PackedConv& p0 = convs[launches[0].conv_slot];
+                    if (!(l.pw_guest >= 0 && pw_active())) { a.pw_wh = nullptr; a.pw_wl = nullptr; }
+                    rc = launch_conv_stem2_f16s3(x, batch, height, width, reinterpret_cast<const _Float16*>(d_weights + p0.w_off),
+                                                 reinterpret_cast<const _Float16*>(d_weights + p0.wl_off), d_weights + p0.s_off, d_weights + p0.b_off,
+                                                 layers[0].leaky ? 1 : 0, a, s);
+                } else {
+                    if (tune_now) { rc = tune_launch(li, a, batch, s); if (rc) return rc; }      // (never reached for the fused stem launch)
                     rc = launch_split_variant(a, pc, tune_now && tuning[li] >= 0 ? tuning[li] : variant_for(l, batch), s);
                 }
                 break;
             }
             case LK_STEM: {
+                if (stem2_active()) break;                              // computed inside layer 1's kernel
                 const Layer& L = layers[l.layer];
                 const PackedConv& pc = convs[l.conv_slot];
                 const View o = view_of(l.out_layer);
@@ -1027,6 +1046,7 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
     const int64_t in_b = (int64_t)L.hin * L.win * L.cin * 4, out_b = (int64_t)L.hout * L.wout * L.cout * 4;
     switch (l.kind) {
         case LK_STEM:
+            if (stem2_active()) { o->bytes_per_frame = 0; break; }                   // accounted on layer 1's launch
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
             o->bytes_per_frame = in_b + out_b;
             o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
@@ -1038,6 +1058,13 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
             o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
             o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);
             o->weight_bytes = ((int64_t)L.cout * L.cin * L.size * L.size + L.cout) * 4;
+            if (idx == 1 && stem2_active()) {                                        // fused stem: its FLOPs ride here, its output is never written
+                const Layer& S = layers[0];
+                o->variant = 100 + STEM2_VARIANT;
+                o->flops_per_frame += 2ll * S.hout * S.wout * S.cout * S.cin * S.size * S.size;
+                o->bytes_per_frame = (int64_t)S.hin * S.win * S.cin * 4 + out_b;
+                o->weight_bytes += ((int64_t)S.cout * S.cin * S.size * S.size + S.cout) * 4;
+            }
             if (l.pw_guest >= 0 && pw_active()) {
                 const Layer& G = layers[launches[l.pw_guest].layer];
                 o->fused_pointwise = 1;
@@ -1067,7 +1094,7 @@ std::string Plan::describe() const {
         os << "],\"anchors\":[";
         for (size_t a = 0; a < L.anchors.size(); ++a) os << (a ? "," : "") << "[" << L.anchors[a].first << "," << L.anchors[a].second << "]";
         os << "],\"classes\":" << L.classes << ",\"row_offset\":" << L.row_offset << ",\"rows\":" << L.rows << ",\"w_off\":" << L.w_off
-           << ",\"fused_into\":" << L.fused_into << ",\"fused_away\":" << (L.fused_away ? "true" : "false") << ",\"alias_of\":" << L.alias_of
+           << ",\"fused_into\":" << ((i == 0 && stem2_active()) ? 1 : L.fused_into) << ",\"fused_away\":" << (L.fused_away ? "true" : "false") << ",\"alias_of\":" << L.alias_of
            << ",\"buf\":" << L.buf << ",\"coff\":" << L.coff << "}";
     }
     os << "],\"bufs\":[";

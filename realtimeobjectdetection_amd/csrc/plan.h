@@ -89,6 +89,7 @@ struct Plan {
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
     bool opt_pw_kernel = false;       // streaming kernel for the stand-alone 1x1 layers it supports (measured slower than the LDS-tiled kernels on the
                                       // pixel-major activation layout: 64-byte half-line loads; kept as an option)
+    bool opt_stem2_kernel = true;     // stem + layer 1 (+ hosted 1x1) in one kernel when the cfg starts like Darknet-53 (split-f16 plans)
     bool opt_patch_kernel = true;     // 2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers
     bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
     bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
@@ -120,7 +121,9 @@ struct Plan {
     std::map<std::vector<int>, int> tune_cache;
     int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
-    bool pw_active() const;                     // fused pointwise convs in use (precision 1, RTOD_NO_PW unset)
+    bool pw_active() const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
+    bool stem2_pattern = false;                 // launches 0 / 1 are a stem and the stride-2 conv conv_stem2_f16s3 fuses (set by plan_buffers)
+    bool stem2_active() const;                  // ... and the plan runs them fused (split-f16 precision, option stem2_kernel)
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)
     std::string describe() const;
     void fill_launch_info(int idx, rtod_launch_info* o, int batch) const;

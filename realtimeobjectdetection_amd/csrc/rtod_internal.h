@@ -135,6 +135,13 @@ constexpr int RING_VARIANT_BASE = 70;      // variant ids >= this: RING_VARIANT_
 const ConvVariantInfo& conv_ring_mode_info(int mode);
 int conv_ring_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s);
+// Stem + first stride-2 convolution (+ hosted 1x1) in one persistent kernel (conv_stem2_f16s3.hip): the stem's output never
+// leaves the CU.  Bit-identical to the stand-alone kernels.
+constexpr int STEM2_VARIANT = 130;         // variant id reported for the fused launch
+bool conv_stem2_supported(int k0, int s0, int p0, int cin0, int cout0, int k1, int s1, int p1, int cout1, int pw_cout);
+int conv_stem2_kernel_name(int pw, char* buf, size_t len);
+int launch_conv_stem2_f16s3(const float* x, int B, int H, int W, const _Float16* w0h, const _Float16* w0l, const float* inv0, const float* bias0,
+                            int leaky0, const ConvArgs& c1, hipStream_t s);
 // 2-D tiled 3x3 stride-1 kernel with an LDS-resident input patch (conv_patch_f16s3.hip): for images too wide for the band
 // kernel; bit-identical to the generic / ring tiles, so its modes are further autotune candidates of those layers.
 constexpr int PATCH_MODES = 4;

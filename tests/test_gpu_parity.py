@@ -377,6 +377,27 @@ def test_fused_pointwise_epilogue_is_bit_identical(tmp_path_factory, monkeypatch
     assert torch.equal(ya, yb)
 
 
+@pytest.mark.parametrize("res,batch", [(416, 2), (608, 1), (96, 3)])
+def test_fused_stem_kernel_is_bit_identical(tmp_path_factory, res, batch):
+    """conv_stem2_f16s3 computes the stem inside layer 1's kernel (the 608x608x32 stem output never reaches HBM) with the
+    stand-alone kernels' arithmetic: switching it off (plan option stem2_kernel = 0) must not change a bit of the output,
+    with and without the hosted 1x1 conv of layer 2."""
+    x = torch.from_numpy(synth.synth_frames(batch, res, seed=5)).cuda()
+    outs = []
+    for tag, opts in (("s2_on", {}), ("s2_off", {"stem2_kernel": 0}), ("s2_on_nopw", {"fuse_pointwise": 0}),
+                      ("s2_off_nopw", {"stem2_kernel": 0, "fuse_pointwise": 0})):
+        m = _fresh_f16s3(tmp_path_factory, "%s_%d" % (tag, res), res)
+        m.options.update(opts)
+        with torch.no_grad():
+            outs.append(m(x).clone())
+        fused = [li for li in m.launch_infos() if li.variant == 230]
+        assert len(fused) == (0 if "stem2_kernel" in opts else 1), (tag, [li.variant for li in m.launch_infos()][:4])
+        assert not m.overflowed()
+        del m
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
 def test_two_plans_on_two_streams_match_single_stream(tmp_path_factory):
     """bench.py keeps two batches in flight: two plans (own arenas) on two HIP streams, write_results on a third.
     Interleaved execution must give exactly the single-stream results."""
