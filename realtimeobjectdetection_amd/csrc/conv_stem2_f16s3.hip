@@ -8,8 +8,12 @@
 // 0.12 + 0.19 ms of a 4.2 ms forward for 3 % of its FLOPs.  Here s never leaves the CU.
 //
 // A persistent workgroup (8 waves, one per CU) walks 8 x 16 tiles of o1.  Per tile:
+//   0. input patch: the 3 x 19 x 35 input values under the tile are fetched one tile ahead (coalesced rows, 4 values per
+//      thread), split ONCE into (hi | lo << 16) f16 pairs of 8*x and kept in LDS (8 KB) — the stem's 27 taps re-read every
+//      input value 9 times, so converting at the gather costs 9x the vector work;
 //   1. stem phase: the 17 x 33 pixels of s the tile touches are computed 16 pixels at a time — the 27-tap dot product is
-//      one k32 step of v_mfma_f32_16x16x32_f16 in the split arithmetic of conv_stem.hip (x*8 = xh + xl, three products) —
+//      one k32 step of v_mfma_f32_16x16x32_f16 in the split arithmetic of conv_stem.hip (x*8 = xh + xl, three products),
+//      operands gathered from the input patch (8 ds_read_b32 + 8 v_perm per 16 pixels) —
 //      scaled / biased / activated / split exactly as conv_stem_split_kernel does, and written to an LDS patch in the
 //      activation format (hi plane, lo plane, 64-byte rows, chunk swizzle).  Pixels outside the image are written as zeros
 //      (layer 1's padding).  Columns are stored even-then-odd per patch row, so the stride-2 taps read 16 CONSECUTIVE rows;
@@ -33,10 +37,14 @@ constexpr int S2_PE = S2_PR * S2_PC;                                   // 561
 constexpr int S2_GROUPS = (S2_PE + 15) / 16;                           // 36 groups of 16 patch pixels
 constexpr int S2_PROWS = S2_GROUPS * 16, S2_PLANE = S2_PROWS * 64;     // 576 rows, 36 864 bytes per plane
 constexpr int S2_W1 = 9 * 64 * 64;                                     // one plane of layer 1's weights in LDS: [tap][64 rows][64 B]
-constexpr int S2_W2 = 2 * 32 * 64;                                     // one plane of the hosted 1x1 conv: [chunk][32 rows][64 B]
 constexpr int S2_WAVES = 8, S2_NT = S2_WAVES * 64;
 constexpr int S2_GPW = (S2_GROUPS + S2_WAVES - 1) / S2_WAVES;          // pixel groups per wave (5; the last wave slots are idle)
-constexpr int S2_LDS = 2 * S2_PLANE + 2 * S2_W1 + 2 * S2_W2 + (64 + 64 + 32 + 32) * 4;
+constexpr int S2_IR = S2_PR + 2, S2_IC = S2_PC + 2;                     // 19 x 35 input pixels under the patch
+constexpr int S2_IN = 3 * S2_IR * S2_IC;                               // 1995 input values
+constexpr int S2_INP = 2048;                                           // padded: dwords S2_IN.. stay zero (operand of the k >= 27 lanes)
+constexpr int S2_VPT = S2_INP / S2_NT;                                 // input values per thread (4)
+constexpr int S2_LDS = 2 * S2_PLANE + 2 * S2_W1 + S2_INP * 4 + (64 + 64 + 32 + 32) * 4;
+static_assert(S2_INP % S2_NT == 0 && S2_INP >= S2_IN + 1, "input patch padding");
 
 struct Stem2Args {
     const float* x; unsigned x_bytes;                 // [B,3,H,W] fp32
@@ -70,8 +78,8 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const patch = smem;                                  // [hi | lo][576][64]
     unsigned char* const w1 = smem + 2 * S2_PLANE;                      // [hi | lo][9][64][64]
-    unsigned char* const w2 = w1 + 2 * S2_W1;                           // [hi | lo][2][32][64]
-    float* const tab = reinterpret_cast<float*>(w2 + 2 * S2_W2);        // inv1*8 [64], bias1*8 [64], inv2*8 [32], bias2*8 [32]
+    unsigned* const inp = reinterpret_cast<unsigned*>(w1 + 2 * S2_W1);  // [3][19][35] (hi | lo << 16) of 8*x, zero tail
+    float* const tab = reinterpret_cast<float*>(inp + S2_INP);          // inv1*8 [64], bias1*8 [64], inv2*8 [32], bias2*8 [32]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -95,20 +103,6 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             const unsigned l = lds0 + (unsigned)(tap * 64 * 64 + rb * 1024);
             s2_dma_pair(rs_wh, rs_wl, vo, (unsigned)tap * (unsigned)c.Npad * 64u, l, l + S2_W1);
         }
-        if constexpr (PW) {
-            const unsigned pwb = (unsigned)c.pw_npad * (unsigned)c.pw_k * 2u;
-            const __amdgpu_buffer_rsrc_t rs_2h = __builtin_amdgcn_make_buffer_rsrc((void*)c.pw_wh, 0, pwb, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_2l = __builtin_amdgcn_make_buffer_rsrc((void*)c.pw_wl, 0, pwb, 0x00020000);
-            const unsigned lds2 = (unsigned)(size_t)w2;
-            for (int p = wave; p < 2 * 2; p += S2_WAVES) {              // (chunk, 16-row block)
-                const int kc = p >> 1, rb = p & 1;
-                const int rho = rb * 16 + lrow;
-                const int ch = (lane & 3) ^ ((rho >> 1) & 3);
-                const unsigned vo = (unsigned)(tr_chan_of_row(rho) * 32 + ch * 8) * 2u;
-                const unsigned l = lds2 + (unsigned)(kc * 32 * 64 + rb * 1024);
-                s2_dma_pair(rs_2h, rs_2l, vo, (unsigned)kc * (unsigned)c.pw_npad * 64u, l, l + S2_W2);
-            }
-        }
         for (int i = tid; i < 64; i += S2_NT) { tab[i] = c.inv_scale[i] * SPLIT_SCALE; tab[64 + i] = c.bias[i] * SPLIT_SCALE; }
         if constexpr (PW)
             for (int i = tid; i < 32; i += S2_NT) { tab[128 + i] = c.pw_inv_scale[i] * SPLIT_SCALE; tab[160 + i] = c.pw_bias[i] * SPLIT_SCALE; }
@@ -117,6 +111,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
     }
 
     // ---- stem constants of this lane: weight fragments (rows in the transposed product's channel order), scale, bias
+    // (x SPLIT_SCALE folded in: a power of two, exact)
     f16x8 w0h[2], w0l[2];
     float inv0[8], bias0[8];
 #pragma unroll
@@ -126,17 +121,29 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
         w0l[t] = *reinterpret_cast<const f16x8*>(a.w0l + n * 32 + lh * 8);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { inv0[e] = a.inv0[8 * lh + e]; bias0[e] = a.bias0[8 * lh + e]; }
-    // tap geometry of this lane's 8 k values (k = 8*lh + e = (ky*3 + kx)*3 + c): element offset from the pixel's
-    // receptive-field corner and the neighbours it needs (conv_stem.hip)
-    int koff[8], need[8];
+    for (int e = 0; e < 8; ++e) { inv0[e] = a.inv0[8 * lh + e] * SPLIT_SCALE; bias0[e] = a.bias0[8 * lh + e] * SPLIT_SCALE; }
+    const float slope0 = a.leaky0 ? 0.1f : 1.0f, slope1 = c.leaky ? 0.1f : 1.0f, slope2 = (PW && c.pw_leaky) ? 0.1f : 1.0f;                        // leaky(v) = max(v, 0.1 v), bit for bit (v > 0 ? v : 0.1 v)
+    // hosted 1x1 conv: its weight fragments live in registers (2 k chunks x 2 channel tiles, hi / lo)
+    f16x8 w2h[2][2], w2l[2][2];
+    if constexpr (PW) {
+#pragma unroll
+        for (int P = 0; P < 2; ++P)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t o = ((int64_t)P * c.pw_npad + tr_chan_of_row(t * 16 + lr)) * 32 + lh * 8;
+                w2h[P][t] = *reinterpret_cast<const f16x8*>(c.pw_wh + o);
+                w2l[P][t] = *reinterpret_cast<const f16x8*>(c.pw_wl + o);
+            }
+    }
+    // input-patch dword of this lane's 8 k values (k = 8*lh + e = (ky*3 + kx)*3 + c) relative to the stem pixel's patch
+    // position; the k >= 27 lanes read the zero tail
+    int koff[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = lh * 8 + e;
         const int tap = k / 3, cc = k - tap * 3;
         const int ky = tap / 3, kx = tap - ky * 3;
-        koff[e] = (cc * (int)plane + ky * W + kx) * 4;
-        need[e] = (ky == 0 ? 1 : 0) | (ky == 2 ? 2 : 0) | (kx == 0 ? 4 : 0) | (kx == 2 ? 8 : 0) | (k >= 27 ? 16 : 0) | 32;
+        koff[e] = k < 27 ? ((cc * S2_IR + ky) * S2_IC + kx) * 4 : -1;
     }
     // patch pixels of this lane's groups: group g = wave + j*8, patch row q = 16*g + lr = py*33 + column slot
     int gpy[S2_GPW], gpx[S2_GPW], gq[S2_GPW];
@@ -149,11 +156,55 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
         gpy[j] = (g < S2_GROUPS && q < S2_PE) ? py : -(1 << 20);      // beyond the patch: never in the image -> zeros
         gpx[j] = cs < S2_EVEN ? 2 * cs : 2 * (cs - S2_EVEN) + 1;
     }
+    // input values of this thread: i = tid + 512 r -> (channel, row, column) of the 3 x 19 x 35 patch (i >= 1995: the zero tail)
+    int in_off[S2_VPT], in_y[S2_VPT], in_x[S2_VPT];
+#pragma unroll
+    for (int r = 0; r < S2_VPT; ++r) {
+        const int i = tid + S2_NT * r;
+        const int cc = i / (S2_IR * S2_IC), rem = i - cc * (S2_IR * S2_IC);
+        const int iy = rem / S2_IC, ix = rem - iy * S2_IC;
+        in_off[r] = (cc * (int)plane + iy * W + ix) * 4;
+        in_y[r] = i < S2_IN ? iy : -(1 << 20);
+        in_x[r] = ix;
+    }
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const int w_lane = lr * 64 + ((lh ^ ((lr >> 1) & 3)) << 4);         // fragment address inside a 16-row weight block
     float amax = 0.f;
     _Float16* const o1 = reinterpret_cast<_Float16*>(c.out) + c.out_coff;
     _Float16* const o2 = PW ? reinterpret_cast<_Float16*>(c.pw_out) + c.pw_out_coff : nullptr;
+
+    // Input gather of one tile: raw fp32, issued two tiles ahead of its use as MFMA operand (one tile in registers, one in LDS)
+    // so that the round trip runs under the MFMA phases.  Values outside the image read as zero (the stem's padding).
+    float xin[S2_VPT];
+    auto gather = [&](int tile) {
+        int u = tile;
+        const int x0 = (u % a.tiles_x) * S2_TW; u /= a.tiles_x;
+        const int y0 = (u % a.tiles_y) * S2_TH;
+        const int b = u / a.tiles_y;
+        const int gy0 = 2 * y0 - 2, gx0 = 2 * x0 - 2;                   // input pixel of patch (0, 0)
+        const int base = (b * 3 * (int)plane + gy0 * W + gx0) * 4;
+#pragma unroll
+        for (int r = 0; r < S2_VPT; ++r) {
+            const bool ok = (unsigned)(gy0 + in_y[r]) < (unsigned)H && (unsigned)(gx0 + in_x[r]) < (unsigned)W;
+            const unsigned vo = ok ? (unsigned)(base + in_off[r]) : 0x80000000u;
+            xin[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, 0, 0));
+        }
+    };
+    auto stage_input = [&]() {                                          // registers -> (hi | lo << 16) pairs in LDS
+#pragma unroll
+        for (int r = 0; r < S2_VPT; ++r) {
+            const float v = xin[r] * SPLIT_SCALE;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            inp[tid + S2_NT * r] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        gather(blockIdx.x);
+        stage_input();
+        if ((int)(blockIdx.x + gridDim.x) < n_tiles) gather(blockIdx.x + gridDim.x);
+    }
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int u = tile;
@@ -166,18 +217,19 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
 #pragma unroll
         for (int j = 0; j < S2_GPW; ++j) {
             if (wave + j * S2_WAVES >= S2_GROUPS) break;                 // wave-uniform
-            const int sy = sy0 + gpy[j], sx = sx0 + gpx[j];
-            const bool inimg = (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-            const int edge = (sy - 1 < 0 ? 1 : 0) | (sy + 1 >= H ? 2 : 0) | (sx - 1 < 0 ? 4 : 0) | (sx + 1 >= W ? 8 : 0) | 16 | (inimg ? 0 : 32);
-            const int base = (b * 3 * (int)plane + (sy - 1) * W + (sx - 1)) * 4;
-            f16x8 xh, xl;
+            const bool inimg = (unsigned)(sy0 + gpy[j]) < (unsigned)H && (unsigned)(sx0 + gpx[j]) < (unsigned)W;
+            const int pb = gpy[j] < 0 ? 0 : (gpy[j] * S2_IC + gpx[j]) * 4;       // input-patch dword of the pixel's receptive-field corner
+            unsigned d[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned vo = (need[e] & edge) ? 0x80000000u : (unsigned)(base + koff[e]);
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vo, 0, 0)) * SPLIT_SCALE;
-                const _Float16 h = (_Float16)v;
-                xh[e] = h; xl[e] = (_Float16)(v - (float)h);
+            for (int e = 0; e < 8; ++e)
+                d[e] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(inp) + (koff[e] < 0 ? S2_IN * 4 : pb + koff[e]));
+            u32x4 uh, ul;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uh[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
+                ul[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
             }
+            const f16x8 xh = __builtin_bit_cast(f16x8, uh), xl = __builtin_bit_cast(f16x8, ul);
             f16x8 ph, pl;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -188,8 +240,8 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = s[e] * inv0[4 * t + e] + bias0[4 * t + e];
-                    if (a.leaky0) v = v > 0.f ? v : v * 0.1f;
-                    v = inimg ? v * SPLIT_SCALE : 0.f;                   // outside the image: layer 1's zero padding
+                    v = fmaxf(v, v * slope0);
+                    v = inimg ? v : 0.f;                                 // outside the image: layer 1's zero padding
                     _Float16 h, l;
                     split_f16(v, h, l, amax);
                     ph[4 * t + e] = h; pl[4 * t + e] = l;
@@ -201,6 +253,11 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             *reinterpret_cast<f16x8*>(patch + S2_PLANE + o) = pl;
         }
         __syncthreads();
+        // the input patch is dead: stage the next tile's (fetched during the previous tile) and fetch the one after it
+        if (tile + (int)gridDim.x < n_tiles) {
+            stage_input();
+            if (tile + 2 * (int)gridDim.x < n_tiles) gather(tile + 2 * gridDim.x);
+        }
 
         // ---- 2. layer 1: this wave's output row (ty = wave), 64 channels
         f32x4 acc[4];
@@ -239,7 +296,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             for (int e = 0; e < 8; ++e) {
                 const float s = e < 4 ? acc[2 * P][e] : acc[2 * P + 1][e - 4];
                 float v = s * (e < 4 ? i0[e] : i1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
-                if (c.leaky) v = v > 0.f ? v : v * 0.1f;
+                v = fmaxf(v, v * slope1);
                 _Float16 h, l;
                 split_f16(v, h, l, amax);
                 ph[e] = h; pl[e] = l;
@@ -250,11 +307,9 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
                 store_act16(q + c.out_ldc, pl, false);
             }
             if constexpr (PW) {                                          // the stored values are the 1x1 conv's operand of k chunk P
-                const unsigned char* wp = w2 + P * 32 * 64 + w_lane;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + t * 1024);
-                    const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + S2_W2 + t * 1024);
+                    const f16x8 wh = w2h[P][t], wl = w2l[P][t];
                     acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, pl, acc2[t], 0, 0, 0);
                     acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ph, acc2[t], 0, 0, 0);
                     acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ph, acc2[t], 0, 0, 0);
@@ -270,7 +325,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             for (int e = 0; e < 8; ++e) {
                 const float s = e < 4 ? acc2[0][e] : acc2[1][e - 4];
                 float v = s * (e < 4 ? i0[e] : i1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
-                if (c.pw_leaky) v = v > 0.f ? v : v * 0.1f;
+                v = fmaxf(v, v * slope2);
                 _Float16 h, l;
                 split_f16(v, h, l, amax);
                 ph[e] = h; pl[e] = l;
