@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help="batches in flight: steps alternate over N plans (own activation arena) on N HIP streams, so one batch's "
                          "partial rounds, prologues and epilogues overlap the other's kernels; 1 = strictly sequential forwards")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="plan option (rtod_plan_set_option) for A/B runs, e.g. --opt k_slices=0; recorded in config.plan_options")
     ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
     return ap.parse_args(argv)
 
@@ -101,7 +103,7 @@ def self_launch(args):
 
 
 # ------------------------------------------------------------------------------------------ model / baselines
-def build_model(res, device, max_batch, precision):
+def build_model(res, device, max_batch, precision, options=None):
     from realtimeobjectdetection_amd import cfgs, synth
     from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
     from realtimeobjectdetection_amd.darknet import Darknet
@@ -114,6 +116,7 @@ def build_model(res, device, max_batch, precision):
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
         m.precision = precision
+        m.options.update(options or {})
         m.load_weights(wpath)
     m.prepare(max_batch, device)
     return m, ir, w, cfg_text
@@ -276,8 +279,9 @@ def run_rank(args):
     from realtimeobjectdetection_amd.shard import FixedGather
     from realtimeobjectdetection_amd.util import write_results, write_results_async
     B, R = args.batch, args.res
-    model, ir, w, cfg_text = build_model(R, dev, B, args.precision)
-    extra = [build_model(R, dev, B, args.precision)[0] for _ in range(max(0, args.inflight - 1))]
+    plan_opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
+    model, ir, w, cfg_text = build_model(R, dev, B, args.precision, plan_opts)
+    extra = [build_model(R, dev, B, args.precision, plan_opts)[0] for _ in range(max(0, args.inflight - 1))]
     models = [model] + extra
     for m_ in models:
         m_.overflow_check = "off"                       # the timed loops never read the range flag; checked once below
@@ -399,7 +403,7 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x2-split (3 MFMA products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "YOLOv3 cfg %dx%d batch=%d per GPU, %s MFMA conv + fused head + GPU NMS (BASELINE configs[%d])"
                                    % (R, R, B, "exact-fp32" if args.precision == "fp32" else "split-f16", 2 if R == 608 else 1),
-                       "precision": args.precision,
+                       "precision": args.precision, "plan_options": plan_opts,
                        "frames_per_step": world * B, "parallelism": "frame-shard x%d" % world,
                        "in_flight_batches": len(models), "write_results": "async (device-side counts, capacity %d rows)" % CAP,
                        "write_results_stream": "same" if args.serial_nms else "second stream",

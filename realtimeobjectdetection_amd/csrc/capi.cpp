@@ -92,13 +92,17 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 }
 
 const char* rtod_conv_variant_name(int variant) {
-    if (variant == 100 + STEM2_VARIANT) return "conv_stem2_f16s3<8x16, stem + 3x3 s2 + 1x1>";
+    if (variant == 100 + STEM2_VARIANT) return "conv_stem2_f16s3<2 x 4x16, stem + 3x3 s2 + 1x1>";
     if (variant >= 100 + PATCH_VARIANT_BASE && variant < 100 + PATCH_VARIANT_BASE + PATCH_MODES) return conv_patch_mode_info(variant - 100 - PATCH_VARIANT_BASE).name;
     if (variant >= 100 + PW_VARIANT_BASE && variant < 100 + PW_VARIANT_BASE + PW_MODES) return conv_pw_mode_info(variant - 100 - PW_VARIANT_BASE).name;
     if (variant >= 100 + RING_VARIANT_BASE && variant < 100 + RING_VARIANT_BASE + RING_MODES) return conv_ring_mode_info(variant - 100 - RING_VARIANT_BASE).name;
     if (variant >= 100 + BAND_VARIANT_BASE && variant < 100 + BAND_VARIANT_BASE + BAND_MODES) return conv_band_mode_info(variant - 100 - BAND_VARIANT_BASE).name;
     if (variant >= 100 && variant < 100 + HV_COUNT) return conv_f16s3_variant_info(variant - 100).name;
-    if (variant < 0 || variant >= CV_COUNT) return "";
+    if (variant < 0 || variant % 10 >= CV_COUNT || variant / 10 > 2) return "";
+    static const char* const kSliced[2][CV_COUNT] = {
+        {"conv_igemm_f32<128x128,w64x64,k-slices>", "conv_igemm_f32<128x64,w64x32,k-slices>", "conv_igemm_f32<64x64,w32x32,k-slices>", "conv_igemm_f32<128x32,w32x32,k-slices>"},
+        {"conv_igemm_f32<128x128,w64x64,wg per k-slice>", "conv_igemm_f32<128x64,w64x32,wg per k-slice>", "conv_igemm_f32<64x64,w32x32,wg per k-slice>", "conv_igemm_f32<128x32,w32x32,wg per k-slice>"}};
+    if (variant >= 10) return kSliced[variant / 10 - 1][variant % 10];
     return conv_variant_info(variant).name;
 }
 

@@ -42,6 +42,7 @@ const char* layer_type_name(int t) {
 Plan::~Plan() {
     for (auto e : events) (void)hipEventDestroy(e);
     if (d_arena) (void)hipFree(d_arena);
+    if (d_scratch) (void)hipFree(d_scratch);
     if (d_weights) (void)hipFree(d_weights);
 }
 
@@ -284,6 +285,8 @@ int Plan::set_option(const char* name, int value) {
     if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
     else if (k == "ring_kernel") flag = &opt_ring_kernel;
     else if (k == "stem2_kernel") flag = &opt_stem2_kernel;
+    else if (k == "k_slices") flag = &opt_k_slices;
+    else if (k == "k_slice_workgroups") flag = &opt_k_slice_workgroups;
     else if (k == "patch_kernel") flag = &opt_patch_kernel;
     else if (k == "pw_kernel") flag = &opt_pw_kernel;
     else if (k == "stem_kernel") flag = &opt_stem_kernel;
@@ -539,6 +542,12 @@ void Plan::layout_weights() {
             pc.pw = opt_pw_kernel && !hosted && L.fused_into < 0 && conv_pw_supported(L.size, L.stride, L.pad, L.cin, L.cout);
         } else {
             pc.w_off = packed_floats; packed_floats += panel;
+            // deep small-grid layers (13x13 ... 52x52 stages, K >= 256): the K sum is formed in slices of 9 chunks (one 3x3 tap
+            // row of 32 channels ... the value only has to be fixed per layer), so that a small batch can give every slice
+            // its own workgroup.  Decided by the layer's shape alone: the same bits at every batch size.
+            // Shorter sums (K = 256 ... 992: the head and route 1x1 convs of those stages) use shorter slices.
+            const int nkc = pc.Kpad / 32;
+            pc.slice_chunks = (!opt_k_slices || L.hout * L.wout > 2704 || nkc < 8) ? 0 : nkc >= 32 ? 9 : nkc >= 16 ? 4 : 2;
         }
         pc.b_off = packed_floats; packed_floats += pc.Npad;
         packed_floats = (packed_floats + 63) / 64 * 64;
@@ -723,6 +732,14 @@ int Plan::load_weights(const float* w, size_t n) {
         RTOD_HIP(hipMalloc((void**)&d_arena, sizeof(float) * (size_t)arena_floats));
         RTOD_HIP(hipMemset(d_arena, 0, sizeof(float) * (size_t)arena_floats));
     }
+    if (!d_scratch) {
+        bool any = false;
+        for (const auto& pc : convs) any = any || (!pc.split && !pc.stem && pc.slice_chunks > 0);
+        if (any) {
+            scratch_floats = 8ll << 20;                                   // 32 MB: L2 / Infinity-Cache resident; larger panels run the in-workgroup schedule
+            RTOD_HIP(hipMalloc((void**)&d_scratch, sizeof(float) * (size_t)scratch_floats));
+        }
+    }
     RTOD_HIP(hipMemcpy(d_weights, packed.data(), sizeof(float) * (size_t)packed_floats, hipMemcpyHostToDevice));
     RTOD_HIP(hipDeviceSynchronize());
     weights_loaded = true;
@@ -737,6 +754,19 @@ int Plan::choose_variant(const Layer& L, int batch) const {
     const int64_t M = (int64_t)batch * L.hout * L.wout;
     const int64_t big = ((M + 127) / 128) * ((L.cout + 127) / 128);
     return big >= 512 ? CV_128x128 : CV_64x64;     // keep >= 2 workgroups per CU in flight
+}
+
+// Schedule of a K-sliced exact-fp32 launch: its own workgroup per slice while the tile grid alone leaves the chip idle
+// (fewer than two 256-thread workgroups per CU) and the slice panels fit the scratch; both schedules give the same bits.
+int Plan::f32_slice_mode(const Launch& l, int batch, int variant) const {
+    const PackedConv& pc = convs[l.conv_slot];
+    if (pc.split || pc.stem || pc.slice_chunks <= 0) return 0;
+    const Layer& L = layers[l.layer];
+    const ConvVariantInfo& vi = conv_variant_info(variant);
+    const int64_t M = (int64_t)batch * L.hout * L.wout;
+    const int64_t tiles = ((M + vi.bm - 1) / vi.bm) * ((L.cout + vi.bn - 1) / vi.bn);
+    const int64_t S = (pc.Kpad / 32 + pc.slice_chunks - 1) / pc.slice_chunks;
+    return (opt_k_slice_workgroups && d_scratch && tiles < 512 && S * M * pc.Npad <= scratch_floats) ? 2 : 1;
 }
 
 int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
@@ -980,7 +1010,13 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 ConvArgs a;
                 rc = build_conv_args(l, batch, out, a);
                 if (rc) return rc;
-                if (!pc.split) rc = launch_conv(a, choose_variant(L, batch), s);
+                if (!pc.split) {
+                    const int v = choose_variant(L, batch);
+                    const int mode = f32_slice_mode(l, batch, v);
+                    a.slice_chunks = mode ? pc.slice_chunks : 0;
+                    if (mode == 2) { a.partial = d_scratch; a.partial_floats = scratch_floats; }
+                    rc = launch_conv(a, v, s);
+                }
                 else if (li == 1 && stem2_active()) {                  // stem + this conv (+ its hosted 1x1) in one kernel
                     const PackedConv& p0 = convs[launches[0].conv_slot];
                     if (!(l.pw_guest >= 0 && pw_active())) { a.pw_wh = nullptr; a.pw_wl = nullptr; }
@@ -1053,7 +1089,8 @@ void Plan::fill_launch_info(int idx, rtod_launch_info* o, int batch) const {
             break;
         case LK_CONV:
             if (l.pw_host >= 0 && pw_active()) { o->bytes_per_frame = 0; break; }    // accounted on the host conv's launch
-            o->variant = convs[l.conv_slot].split ? 100 + variant_for(l, batch) : choose_variant(L, batch);
+            if (convs[l.conv_slot].split) o->variant = 100 + variant_for(l, batch);
+            else { const int v = choose_variant(L, batch); o->variant = v + 10 * f32_slice_mode(l, batch, v); }   // tile + 10 * K-slice schedule
             o->flops_per_frame = 2ll * L.hout * L.wout * L.cout * L.cin * L.size * L.size;
             o->fused_residual = l.in2_layer >= 0; o->fused_decode = l.out_layer == -2;
             o->bytes_per_frame = in_b + out_b + (l.in2_layer >= 0 ? out_b : 0);

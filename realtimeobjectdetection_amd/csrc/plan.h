@@ -63,6 +63,7 @@ struct PackedConv {
     bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
     bool pw = false;                  // runs on conv_pw_f16s3 (stand-alone 1x1 conv, no residual / decode epilogue)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
+    int slice_chunks = 0;             // exact-fp32 panels: K summed in slices of this many 32-wide chunks (0: one chain), conv_igemm_f32.hip
 };
 
 struct Plan {
@@ -78,6 +79,8 @@ struct Plan {
     int64_t arena_floats = 0, packed_floats = 0;
     float* d_arena = nullptr;
     float* d_weights = nullptr;
+    float* d_scratch = nullptr;       // exact-fp32 plans: slice panels of the one-workgroup-per-K-slice schedule
+    int64_t scratch_floats = 0;
     bool weights_loaded = false;
     int train_decode = 0;
     int precision = 0;         // 0 = exact fp32 MFMA, 1 = f16 hi/lo split (3 products)
@@ -89,6 +92,8 @@ struct Plan {
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
     bool opt_pw_kernel = false;       // streaming kernel for the stand-alone 1x1 layers it supports (measured slower than the LDS-tiled kernels on the
                                       // pixel-major activation layout: 64-byte half-line loads; kept as an option)
+    bool opt_k_slices = true;         // exact-fp32 kernels: deep small-grid layers summed in K slices (own workgroups when the grid is small)
+    bool opt_k_slice_workgroups = true;   // ... (off: always the in-workgroup schedule — same bits; A/B and tests)
     bool opt_stem2_kernel = true;     // stem + layer 1 (+ hosted 1x1) in one kernel when the cfg starts like Darknet-53 (split-f16 plans)
     bool opt_patch_kernel = true;     // 2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers
     bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
@@ -121,6 +126,7 @@ struct Plan {
     std::map<std::vector<int>, int> tune_cache;
     int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
+    int f32_slice_mode(const Launch& l, int batch, int variant) const;   // 0 plain, 1 slices inside the workgroup, 2 one workgroup per slice
     bool pw_active() const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
     bool stem2_pattern = false;                 // launches 0 / 1 are a stem and the stride-2 conv conv_stem2_f16s3 fuses (set by plan_buffers)
     bool stem2_active() const;                  // ... and the plan runs them fused (split-f16 precision, option stem2_kernel)

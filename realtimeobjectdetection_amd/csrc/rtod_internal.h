@@ -74,6 +74,11 @@ struct ConvArgs {
     int32_t* ovf = nullptr;                     // split-format producers: device word that gets 1 OR-ed in when an activation saturates the f16 range
     int xcd_by_n = 0;                           // split kernels: workgroup -> XCD by output-channel tile instead of by pixel tile (see launch_band)
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
+    // exact-fp32 kernel only: K slices (conv_igemm_f32.hip).  slice_chunks > 0: the K sum is formed slice by slice (a property of
+    // the layer); partial != nullptr: one workgroup per slice, raw sums to this scratch ([slices][M][Npad] floats), then a reduction
+    int slice_chunks = 0;
+    float* partial = nullptr;
+    int64_t partial_floats = 0;
     // split path, fused trailing 1x1 conv ("pointwise", conv_f16s3_common.h): the workgroup holds every channel of its
     // output pixels (Cout <= BN), so the next layer's 1x1 convolution runs as a second small GEMM in the epilogue
     const _Float16* pw_wh = nullptr;            // [pw_cout..][pw_k] hi / lo planes of the 1x1 conv (its own packed weights)
@@ -109,6 +114,7 @@ struct ConvVariantInfo { int bm, bn; const char* name; };
 const ConvVariantInfo& conv_variant_info(int v);
 int conv_f32_kernel_name(int variant, char* buf, size_t len);
 int launch_conv(const ConvArgs& a, int variant, hipStream_t s);
+int conv_f32_slices(const ConvArgs& a);                                       // K slices of an exact-fp32 launch (1: unsliced)
 enum ConvF16Variant { HV_128x128 = 0, HV_128x64 = 1, HV_64x64 = 2, HV_64x128 = 3, HV_256x128 = 4, HV_128x256 = 5, HV_128x128_8W = 6, HV_128x64_8W = 7, HV_256x128_16W = 8,
                       HV_192x128_8W = 9, HV_96x128_8W = 10, HV_192x128_12W = 11, HV_COUNT };
 const ConvVariantInfo& conv_f16s3_variant_info(int v);

@@ -122,6 +122,43 @@ def test_frames_are_independent_and_variants_agree(tmp_path_factory, precision):
     assert torch.equal(y5[perm], yp)
 
 
+def test_k_slice_schedules_give_the_same_bits(tmp_path_factory):
+    """Exact-fp32 kernels, deep small-grid layers (13x13 / 26x26, K >= 1024): the K sum is formed in slices whose order is
+    a property of the layer.  One workgroup per slice + reduction (small batches: YOLOv3-tiny batch 1 would otherwise run
+    48 workgroups on 256 CUs) and the in-workgroup schedule must agree bit for bit, so that a frame's result does not
+    depend on the batch it rides in; both stay within the oracle tolerance."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    res = 416
+    cfg_text = NETS["yolov3-tiny"]()
+    d = tmp_path_factory.mktemp("kslices")
+    cfg_path = cfgs.write_cfg(str(d / "t.cfg"), cfg_text)
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    ref.load_weight_stream(w)
+    x_cpu = torch.from_numpy(synth.synth_frames(3, res, seed=11))
+    x = x_cpu.cuda()
+    outs, modes = [], []
+    for opts in ({}, {"k_slice_workgroups": 0}, {"k_slices": 0}):
+        m = Darknet(cfg_path, True).eval()
+        m.net_info["height"] = res
+        m.precision = "fp32"
+        m.options.update(opts)
+        m.load_weight_stream(w)
+        with torch.no_grad():
+            y3 = m(x).clone()
+            y1 = m(x[1:2]).clone()
+        assert torch.equal(y3[1:2], y1)
+        outs.append(y3)
+        modes.append(sorted({li.variant // 10 for li in m.launch_infos() if li.kind == 0 and 0 <= li.variant < 100}))
+        del m
+    assert modes[0] == [0, 2] and modes[1] == [0, 1] and modes[2] == [0], modes
+    assert torch.equal(outs[0], outs[1])                       # two schedules of the same summation order
+    with torch.no_grad():
+        want = ref.forward(x_cpu).numpy()
+    for y in outs:                                              # sliced and unsliced orders both meet the tolerance
+        assert rel_err(y.cpu().numpy(), want).max() <= TOL
+
+
 def test_train_mode_decode(tmp_path_factory):
     m, ref = gpu_model("yolov3-tiny", 416, tmp_path_factory)
     x = torch.from_numpy(synth.synth_frames(1, 416))
