@@ -75,10 +75,17 @@ class RefDarknet:
                                      training=False, momentum=0.1, eps=1e-5)
                 if L.leaky:
                     x = F.leaky_relu(x, 0.1)
+                elif L.silu:                       # cfg extension, not reference behaviour: checked against torch's own op
+                    x = F.silu(x)
             elif L.type == "upsample":
-                x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+                if L.nearest:                      # cfg extension (YOLOv5-style blocks)
+                    x = F.interpolate(x, scale_factor=2, mode="nearest")
+                else:
+                    x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
             elif L.type == "maxpool":
-                if L.stride != 1:
+                if L.pool_pad:                     # cfg extension: symmetric -inf padding (SPPF: size 5, stride 1, pad 2)
+                    x = F.max_pool2d(x, L.size, L.stride, L.pool_pad)
+                elif L.stride != 1:
                     x = F.max_pool2d(x, L.size, L.stride)
                 else:
                     x = F.pad(x, (0, L.size - 1, 0, L.size - 1), mode="replicate")

@@ -60,6 +60,9 @@ class Layer:
     pad: int = 0
     bn: bool = False
     leaky: bool = False
+    silu: bool = False             # extension (not in the reference grammar): activation=silu, x * sigmoid(x)
+    nearest: bool = False          # extension: [upsample] mode=nearest (the reference always builds bilinear, darknet.py:589)
+    pool_pad: int = 0              # extension: [maxpool] symmetric=1 -> (size-1)//2 of -inf padding on every side (SPPF pools)
     srcs: Tuple[int, ...] = ()     # absolute source layer indices (route / shortcut)
     anchors: Tuple[Tuple[int, int], ...] = ()
     classes: int = 0
@@ -117,14 +120,20 @@ def build_ir(blocks: List[dict], height: int, width: int = None) -> NetIR:
             L.stride = int(b["stride"])
             L.pad = (L.size - 1) // 2 if int(b["pad"]) else 0
             L.leaky = b["activation"] == "leaky"
+            L.silu = b["activation"] in ("silu", "swish")
             L.hout = (prev_h + 2 * L.pad - L.size) // L.stride + 1
             L.wout = (prev_w + 2 * L.pad - L.size) // L.stride + 1
         elif t == "upsample":
             L.cout, L.hout, L.wout, L.stride = prev_c, prev_h * 2, prev_w * 2, 2
+            L.nearest = b.get("mode", "bilinear") == "nearest"
         elif t == "maxpool":
             L.size, L.stride = int(b["size"]), int(b["stride"])
             L.cout = prev_c
-            if L.stride != 1:
+            if int(b.get("symmetric", 0)):
+                L.pool_pad = (L.size - 1) // 2
+                L.hout = (prev_h + 2 * L.pool_pad - L.size) // L.stride + 1
+                L.wout = (prev_w + 2 * L.pool_pad - L.size) // L.stride + 1
+            elif L.stride != 1:
                 L.hout = (prev_h - L.size) // L.stride + 1
                 L.wout = (prev_w - L.size) // L.stride + 1
             else:  # MaxPoolStride1: replicate-pad right/bottom by size-1, then size/1 pool

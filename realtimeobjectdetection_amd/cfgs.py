@@ -132,6 +132,35 @@ def mini_fallback_cfg(height=64, width=64, classes=3) -> str:
     return "\n".join(L) + "\n"
 
 
+def v5_style_mini_cfg(height=128, width=128, classes=80, act="silu") -> str:
+    """YOLOv5-style building blocks in the (extended) cfg grammar — NOT a reference network.  The reference's YOLOv5 path is a
+    torch.hub fetch (detect.py:255-285) whose model source does not exist offline, so no YOLOv5 graph can be pinned; this cfg
+    exercises the kernel-level pieces such a graph needs, each checked against PyTorch's own CPU op (parity unpinned):
+    a 6x6 stride-2 pad-2 stem, SiLU activations (also on a residual block and on the hosted / fused epilogues), an SPPF-like
+    run of 5x5 stride-1 pad-2 max-pools joined by routes, and nearest x2 upsampling.  Extension keys: activation=silu,
+    [maxpool] symmetric=1, [upsample] mode=nearest.  Every conv after the stem has Cin % 32 == 0; with ``act="leaky"`` the graph
+    is expressible in the split-f16 format (SiLU epilogues exist on the exact-fp32 kernels only)."""
+    nout = 3 * (5 + classes)
+    L = _net(height, width)
+    L += _conv(32, 6, 2, act=act)                                    # 0: 6x6 / 2 stem (pad = (6 - 1) // 2 = 2), 32 @ H/2
+    L += _conv(64, 3, 2, act=act)                                    # 1: 64 @ H/4
+    L += _conv(32, 1, 1, act=act) + _conv(64, 3, 1, act=act) + _shortcut(-3)      # 2-4: bottleneck with shortcut
+    L += _conv(128, 3, 2, act=act)                                   # 5: 128 @ H/8
+    L += _conv(256, 3, 2, act=act)                                   # 6: 256 @ H/16
+    L += _conv(128, 1, 1, act=act)                                   # 7: SPPF entry, 128 @ H/16
+    L += ["[maxpool]", "size=5", "stride=1", "symmetric=1", ""]         # 8
+    L += _route(-1, -2)                                                 # 9: pooled + entry, 256 ch
+    L += ["[maxpool]", "size=5", "stride=1", "symmetric=1", ""]         # 10: pool of the concat (9x9 receptive field on half of it)
+    L += _conv(256, 1, 1, act=act)                                   # 11
+    L += _conv(nout, 1, 1, bn=False, act="linear") + _yolo((6, 7, 8), _ANCHORS_V3, 9, classes)   # 12, 13: head at stride 16
+    L += _route(-3) + _conv(128, 1, 1, act=act)                      # 14, 15
+    L += ["[upsample]", "stride=2", "mode=nearest", ""]                 # 16: 128 @ H/8
+    L += _route(-1, 5)                                                  # 17: 256 @ H/8
+    L += _conv(128, 1, 1, act=act) + _conv(256, 3, 1, act=act)    # 18, 19
+    L += _conv(nout, 1, 1, bn=False, act="linear") + _yolo((3, 4, 5), _ANCHORS_V3, 9, classes)   # 20, 21: head at stride 8
+    return "\n".join(L) + "\n"
+
+
 def write_cfg(path, text):
     with open(path, "w") as f:
         f.write(text)

@@ -192,7 +192,9 @@ int launch_copy(const View& a, const View& out, int B, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // max-pool: size/stride floor mode (nn.MaxPool2d, src/darknet.py:547-555); stride 1 = MaxPoolStride1
 // (src/darknet.py:17-46): replicate-pad right/bottom by size-1 then size/1 pool == clamp the window.
-__global__ void maxpool_kernel(View in, View out, int B, int size, int stride) {
+// pad > 0 (cfg extension `symmetric=1`, SPPF-style pools): the window starts pad pixels up / left and out-of-image taps
+// count as -inf (nn.MaxPool2d(size, stride, pad)).
+__global__ void maxpool_kernel(View in, View out, int B, int size, int stride, int pad) {
     const int C4 = in.C / 4;
     const int64_t total = (int64_t)B * out.H * out.W * C4;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -203,9 +205,11 @@ __global__ void maxpool_kernel(View in, View out, int B, int size, int stride) {
         const int b = (int)(p / out.H);
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int dy = 0; dy < size; ++dy) {
-            int iy = oy * stride + dy; if (iy > in.H - 1) iy = in.H - 1;
+            int iy = oy * stride + dy - pad;
+            if (pad) { if ((unsigned)iy >= (unsigned)in.H) continue; } else if (iy > in.H - 1) iy = in.H - 1;
             for (int dx = 0; dx < size; ++dx) {
-                int ix = ox * stride + dx; if (ix > in.W - 1) ix = in.W - 1;
+                int ix = ox * stride + dx - pad;
+                if (pad) { if ((unsigned)ix >= (unsigned)in.W) continue; } else if (ix > in.W - 1) ix = in.W - 1;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(in.base + in.coff + c + (((int64_t)b * in.H + iy) * in.W + ix) * in.ldc);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
@@ -215,12 +219,95 @@ __global__ void maxpool_kernel(View in, View out, int B, int size, int stride) {
     }
 }
 
-int launch_maxpool(const View& in, const View& out, int B, int size, int stride, hipStream_t s) {
-    if (in.split || out.split) { set_error("maxpool: split-format views unsupported (use precision fp32)"); return RTOD_E_ARG; }
-    if (!view_ok4(in) || !view_ok4(out) || in.C != out.C || size < 1 || stride < 1) { set_error("maxpool: bad views"); return RTOD_E_ARG; }
+// split-format variant: the maximum is taken over hi + lo (exact in fp32: 22 significant bits) and the winning element's
+// (hi, lo) pair is stored as it stands — no re-split, no rounding.  8 channels (16 B of each plane) per thread.
+__global__ void maxpool_split_kernel(View in, View out, int B, int size, int stride, int pad) {
+    const int C8 = in.C / 8;
+    const int64_t total = (int64_t)B * out.H * out.W * C8;
+    const _Float16* ib = reinterpret_cast<const _Float16*>(in.base);
+    _Float16* ob = reinterpret_cast<_Float16*>(out.base);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C8) * 8;
+        int64_t p = t / C8;
+        const int ox = (int)(p % out.W); p /= out.W;
+        const int oy = (int)(p % out.H);
+        const int b = (int)(p / out.H);
+        float m[8];
+        f16x8a mh, ml;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; mh[e] = (_Float16)0.f; ml[e] = (_Float16)0.f; }
+        for (int dy = 0; dy < size; ++dy) {
+            int iy = oy * stride + dy - pad;
+            if (pad) { if ((unsigned)iy >= (unsigned)in.H) continue; } else if (iy > in.H - 1) iy = in.H - 1;
+            for (int dx = 0; dx < size; ++dx) {
+                int ix = ox * stride + dx - pad;
+                if (pad) { if ((unsigned)ix >= (unsigned)in.W) continue; } else if (ix > in.W - 1) ix = in.W - 1;
+                const _Float16* q = ib + (((int64_t)b * in.H + iy) * in.W + ix) * 2 * in.ldc + in.coff + c;
+                const f16x8a h = *reinterpret_cast<const f16x8a*>(q);
+                const f16x8a l = *reinterpret_cast<const f16x8a*>(q + in.ldc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)h[e] + (float)l[e];
+                    if (v > m[e]) { m[e] = v; mh[e] = h[e]; ml[e] = l[e]; }
+                }
+            }
+        }
+        _Float16* o = ob + (((int64_t)b * out.H + oy) * out.W + ox) * 2 * out.ldc + out.coff + c;
+        *reinterpret_cast<f16x8a*>(o) = mh;
+        *reinterpret_cast<f16x8a*>(o + out.ldc) = ml;
+    }
+}
+
+int launch_maxpool(const View& in, const View& out, int B, int size, int stride, int pad, hipStream_t s) {
+    if (in.split != out.split) { set_error("maxpool: mixed activation formats"); return RTOD_E_ARG; }
+    if (in.C != out.C || size < 1 || stride < 1 || pad < 0 || pad >= size) { set_error("maxpool: bad geometry"); return RTOD_E_ARG; }
+    const int eh = pad ? (in.H + 2 * pad - size) / stride + 1 : (stride != 1 ? (in.H - size) / stride + 1 : in.H);
+    const int ew = pad ? (in.W + 2 * pad - size) / stride + 1 : (stride != 1 ? (in.W - size) / stride + 1 : in.W);
+    if (out.H != eh || out.W != ew) { set_error("maxpool: output %dx%d, expected %dx%d", out.H, out.W, eh, ew); return RTOD_E_ARG; }
+    if (in.split) {
+        if (!in.base || !out.base || in.C % 8 || in.coff % 8 || out.coff % 8 || in.ldc % 8 || out.ldc % 8) { set_error("maxpool: bad split views"); return RTOD_E_ARG; }
+        const int64_t total = (int64_t)B * out.H * out.W * (in.C / 8);
+        hipLaunchKernelGGL(maxpool_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B, size, stride, pad);
+        return hip_fail(hipGetLastError(), "maxpool_split launch");
+    }
+    if (!view_ok4(in) || !view_ok4(out)) { set_error("maxpool: bad views"); return RTOD_E_ARG; }
     const int64_t total = (int64_t)B * out.H * out.W * (in.C / 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B, size, stride);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B, size, stride, pad);
     return hip_fail(hipGetLastError(), "maxpool launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// nearest x2 (cfg extension `[upsample] mode=nearest`; nn.Upsample(scale_factor=2, mode="nearest")): out(y, x) = in(y/2, x/2).
+// A pure copy in either activation format (split: both planes move unchanged).
+__global__ void upsample_nearest2x_kernel(View in, View out, int B) {
+    const int per = in.split ? 8 : 4;                         // channels per thread: 16 bytes of a plane / of the fp32 pixel
+    const int CV = in.C / per;
+    const int64_t total = (int64_t)B * out.H * out.W * CV;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % CV) * per;
+        int64_t p = t / CV;
+        const int ox = (int)(p % out.W); p /= out.W;
+        const int oy = (int)(p % out.H);
+        const int b = (int)(p / out.H);
+        const int64_t ip = ((int64_t)b * in.H + (oy >> 1)) * in.W + (ox >> 1), op = ((int64_t)b * out.H + oy) * out.W + ox;
+        if (in.split) {
+            const _Float16* q = reinterpret_cast<const _Float16*>(in.base) + ip * 2 * in.ldc + in.coff + c;
+            _Float16* o = reinterpret_cast<_Float16*>(out.base) + op * 2 * out.ldc + out.coff + c;
+            *reinterpret_cast<f16x8a*>(o) = *reinterpret_cast<const f16x8a*>(q);
+            *reinterpret_cast<f16x8a*>(o + out.ldc) = *reinterpret_cast<const f16x8a*>(q + in.ldc);
+        } else {
+            *reinterpret_cast<f32x4*>(out.base + out.coff + c + op * out.ldc) = *reinterpret_cast<const f32x4*>(in.base + in.coff + c + ip * in.ldc);
+        }
+    }
+}
+
+int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_t s) {
+    if (!in.base || !out.base || in.split != out.split || in.C != out.C || out.H != 2 * in.H || out.W != 2 * in.W) { set_error("upsample_nearest: bad views"); return RTOD_E_ARG; }
+    const int per = in.split ? 8 : 4;
+    if (in.C % per || in.coff % per || out.coff % per || in.ldc % per || out.ldc % per) { set_error("upsample_nearest: channel alignment"); return RTOD_E_ARG; }
+    const int64_t total = (int64_t)B * out.H * out.W * (in.C / per);
+    hipLaunchKernelGGL(upsample_nearest2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, B);
+    return hip_fail(hipGetLastError(), "upsample_nearest launch");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ __device__ __forceinline__ float decode_value(const DecodeArgs& d, float v, int 
 __device__ __forceinline__ void conv_f32_store(const ConvArgs& a, int m, int n, float raw, int hw, float& amax) {
 #pragma clang fp contract(off)
     float v = raw + a.bias[n];
-    if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+    v = apply_act(v, a.leaky);
     if (a.res) v += a.res[(int64_t)m * a.res_ldc + a.res_coff + n];
     if (a.dec.enabled) {
         const int b = m / hw, cell = m - b * hw;

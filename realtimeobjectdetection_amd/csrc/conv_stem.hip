@@ -74,7 +74,7 @@ void conv_stem_kernel(const StemArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[e] + bias;
-                if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+                v = apply_act(v, a.leaky);
                 Tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + lr] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the wave's own LDS writes, then reads (in order)
@@ -229,7 +229,7 @@ void conv_stem_split_kernel(const StemSplitArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[i][j][e] * inv[j] + bias[j];
-                        if (a.leaky) v = v > 0.f ? v : v * 0.1f;
+                        v = apply_act(v, a.leaky);
                         Tw[(i * 16 + 4 * lh + e) * 36 + j * 16 + lr] = v;
                     }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the wave's own LDS writes, then reads (in order)

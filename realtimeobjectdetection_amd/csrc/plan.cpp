@@ -138,16 +138,23 @@ int Plan::parse(const std::string& text) {
             auto act = b.kv.find("activation");
             if (act == b.kv.end()) { set_error("cfg: layer %d: missing activation", i); return RTOD_E_CFG; }
             L.leaky = act->second == "leaky";
+            L.act = L.leaky ? 1 : (act->second == "silu" || act->second == "swish") ? 2 : 0;    // silu: cfg extension
             if (L.cout < 1 || L.size < 1 || L.stride < 1) { set_error("cfg: layer %d: bad conv geometry", i); return RTOD_E_CFG; }
         } else if (b.type == "upsample") {
             L.type = LT_UPSAMPLE;
             int st = 0;
             CFG_INT(b, "stride", st);   // parsed but ignored: scale_factor=2 is hard-coded (darknet.py:589-592)
             L.stride = 2;
+            auto md = b.kv.find("mode");                 // cfg extension: mode=nearest (default: the reference's bilinear)
+            L.nearest = md != b.kv.end() && md->second == "nearest";
         } else if (b.type == "maxpool") {
             L.type = LT_MAXPOOL;
             CFG_INT(b, "size", L.size);
             CFG_INT(b, "stride", L.stride);
+            int sym = 0;
+            auto sy = b.kv.find("symmetric");            // cfg extension: -inf padding of (size-1)/2 on every side
+            if (sy != b.kv.end() && to_int(sy->second, sym) && sym) L.pool_pad = (L.size - 1) / 2;
+            if (L.size < 1 || L.stride < 1) { set_error("cfg: layer %d: bad pool geometry", i); return RTOD_E_CFG; }
         } else if (b.type == "shortcut") {
             L.type = LT_SHORTCUT;
             int from = 0;
@@ -214,7 +221,8 @@ int Plan::resolve_shapes() {
             case LT_UPSAMPLE: L.cout = pc; L.hout = 2 * ph; L.wout = 2 * pw; break;
             case LT_MAXPOOL:
                 L.cout = pc;
-                if (L.stride != 1) { L.hout = (ph - L.size) / L.stride + 1; L.wout = (pw - L.size) / L.stride + 1; }
+                if (L.pool_pad) { L.hout = (ph + 2 * L.pool_pad - L.size) / L.stride + 1; L.wout = (pw + 2 * L.pool_pad - L.size) / L.stride + 1; }
+                else if (L.stride != 1) { L.hout = (ph - L.size) / L.stride + 1; L.wout = (pw - L.size) / L.stride + 1; }
                 else { L.hout = ph; L.wout = pw; }
                 if (L.hout < 1 || L.wout < 1) { set_error("cfg: layer %d: empty pool output", i); return RTOD_E_CFG; }
                 break;
@@ -464,7 +472,7 @@ int Plan::plan_buffers() {
         const Layer& L0 = layers[0]; const Layer& L1 = layers[1];
         int pwc = 0;
         if (launches[1].pw_guest >= 0) pwc = layers[launches[launches[1].pw_guest].layer].cout;
-        stem2_pattern = L0.bn && L1.bn && conv_stem2_supported(L0.size, L0.stride, L0.pad, L0.cin, L0.cout, L1.size, L1.stride, L1.pad, L1.cout, pwc) &&
+        stem2_pattern = L0.bn && L1.bn && L0.act <= 1 && L1.act <= 1 && (launches[1].pw_guest < 0 || layers[launches[launches[1].pw_guest].layer].act <= 1) && conv_stem2_supported(L0.size, L0.stride, L0.pad, L0.cin, L0.cout, L1.size, L1.stride, L1.pad, L1.cout, pwc) &&
                         (pwc == 0 || pwc == 32);
     }
     // liveness per buffer over launch time (= layer index of the launch)
@@ -500,9 +508,13 @@ int Plan::check_split_supported() const {
     // precision 1 keeps every activation in the split f16 format: every conv but the stem must read
     // 32-channel K-chunks, every shortcut / head must ride a conv epilogue, concats must be zero-copy
     for (const auto& l : launches) {
-        if (l.kind == LK_ADD || l.kind == LK_COPY || l.kind == LK_MAXPOOL || l.kind == LK_DECODE) {
+        if (l.kind == LK_ADD || l.kind == LK_COPY || l.kind == LK_DECODE) {       // (max-pool and both upsamples have split-format kernels)
             set_error("precision f16s3 unsupported for this cfg (layer %d needs a stand-alone %s kernel); use fp32", l.layer,
-                      l.kind == LK_ADD ? "add" : l.kind == LK_COPY ? "copy" : l.kind == LK_MAXPOOL ? "maxpool" : "decode");
+                      l.kind == LK_ADD ? "add" : l.kind == LK_COPY ? "copy" : "decode");
+            return RTOD_E_CFG;
+        }
+        if ((l.kind == LK_CONV || l.kind == LK_STEM) && layers[l.layer].act == 2 && l.layer > 0) {
+            set_error("precision f16s3 unsupported for this cfg (layer %d: activation=silu runs on the exact-fp32 kernels only); use fp32", l.layer);
             return RTOD_E_CFG;
         }
         if (l.kind == LK_CONV && l.layer > 0) {
@@ -804,7 +816,7 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
         a.inv_scale = d_weights + pc.s_off;
     }
     a.kh = a.kw = L.size; a.stride = L.stride; a.pad = L.pad;
-    a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.leaky ? 1 : 0;
+    a.Ho = L.hout; a.Wo = L.wout; a.Cout = L.cout; a.leaky = L.act;
     a.ovf = overflow_flag;
     if (in.C != pc.cin_p || in.H != L.hin || in.W != L.win) { set_error("forward: layer %d input view mismatch", l.layer); return RTOD_E_STATE; }
     if (l.out_layer == -2) { a.out = out; a.dec = l.dec; a.dec.train = train_decode; }
@@ -828,7 +840,7 @@ int Plan::build_conv_args(const Launch& l, int batch, float* out, ConvArgs& a) c
         a.pw_wl = reinterpret_cast<const _Float16*>(d_weights + gc.wl_off);
         a.pw_inv_scale = d_weights + gc.s_off; a.pw_bias = d_weights + gc.b_off;
         a.pw_out = o.base; a.pw_out_ldc = o.ldc; a.pw_out_coff = o.coff;
-        a.pw_cout = G.cout; a.pw_k = L.cout; a.pw_leaky = G.leaky ? 1 : 0; a.pw_npad = gc.Npad;
+        a.pw_cout = G.cout; a.pw_k = L.cout; a.pw_leaky = G.act; a.pw_npad = gc.Npad;
     }
     return RTOD_OK;
 }
@@ -1022,7 +1034,7 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                     if (!(l.pw_guest >= 0 && pw_active())) { a.pw_wh = nullptr; a.pw_wl = nullptr; }
                     rc = launch_conv_stem2_f16s3(x, batch, height, width, reinterpret_cast<const _Float16*>(d_weights + p0.w_off),
                                                  reinterpret_cast<const _Float16*>(d_weights + p0.wl_off), d_weights + p0.s_off, d_weights + p0.b_off,
-                                                 layers[0].leaky ? 1 : 0, a, s);
+                                                 layers[0].act, a, s);
                 } else {
                     if (tune_now) { rc = tune_launch(li, a, batch, s); if (rc) return rc; }      // (never reached for the fused stem launch)
                     rc = launch_split_variant(a, pc, tune_now && tuning[li] >= 0 ? tuning[li] : variant_for(l, batch), s);
@@ -1037,14 +1049,17 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                 if (pc.split)
                     rc = launch_conv_stem_split(x, reinterpret_cast<const _Float16*>(d_weights + pc.w_off), reinterpret_cast<const _Float16*>(d_weights + pc.wl_off),
                                                 d_weights + pc.s_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
-                                                L.stride, L.cout, L.leaky ? 1 : 0, overflow_flag, s);
+                                                L.stride, L.cout, L.act, overflow_flag, s);
                 else
                     rc = launch_conv_stem(x, d_weights + pc.w_off, d_weights + pc.b_off, o, batch, height, width, L.hout, L.wout,
-                                          L.stride, L.cout, L.leaky ? 1 : 0, s);
+                                          L.stride, L.cout, L.act, s);
                 break;
             }
-            case LK_UPSAMPLE: rc = launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s); break;
-            case LK_MAXPOOL: rc = launch_maxpool(view_of(l.in_layer), view_of(l.out_layer), batch, layers[l.layer].size, layers[l.layer].stride, s); break;
+            case LK_UPSAMPLE:
+                rc = layers[l.layer].nearest ? launch_upsample_nearest2x(view_of(l.in_layer), view_of(l.out_layer), batch, s)
+                                             : launch_upsample2x(view_of(l.in_layer), view_of(l.out_layer), batch, s);
+                break;
+            case LK_MAXPOOL: rc = launch_maxpool(view_of(l.in_layer), view_of(l.out_layer), batch, layers[l.layer].size, layers[l.layer].stride, layers[l.layer].pool_pad, s); break;
             case LK_ADD: rc = launch_add(view_of(l.in_layer), view_of(l.in2_layer), view_of(l.out_layer), batch, s); break;
             case LK_COPY: {
                 const View in = view_of(l.in_layer);
@@ -1125,7 +1140,7 @@ std::string Plan::describe() const {
         if (i) os << ",";
         os << "{\"index\":" << L.index << ",\"type\":\"" << layer_type_name(L.type) << "\",\"cin\":" << L.cin << ",\"cout\":" << L.cout
            << ",\"hin\":" << L.hin << ",\"win\":" << L.win << ",\"hout\":" << L.hout << ",\"wout\":" << L.wout << ",\"size\":" << L.size
-           << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"bn\":" << (L.bn ? "true" : "false") << ",\"leaky\":" << (L.leaky ? "true" : "false")
+           << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"bn\":" << (L.bn ? "true" : "false") << ",\"leaky\":" << (L.leaky ? "true" : "false") << ",\"act\":" << L.act << ",\"nearest\":" << (L.nearest ? "true" : "false") << ",\"pool_pad\":" << L.pool_pad
            << ",\"srcs\":[";
         for (size_t s = 0; s < L.srcs.size(); ++s) os << (s ? "," : "") << L.srcs[s];
         os << "],\"anchors\":[";

@@ -18,6 +18,9 @@ struct Layer {
     int cin = 0, cout = 0, hin = 0, win = 0, hout = 0, wout = 0;
     int size = 0, stride = 1, pad = 0;
     bool bn = false, leaky = false;
+    int act = 0;                  // 0 linear, 1 leaky(0.1), 2 SiLU (cfg extension); leaky == (act == 1)
+    bool nearest = false;         // upsample: mode=nearest (cfg extension; the reference builds bilinear)
+    int pool_pad = 0;             // maxpool: symmetric=1 -> (size-1)/2 of -inf padding per side (cfg extension)
     std::vector<int> srcs;                       // absolute layer indices (route / shortcut)
     std::vector<std::pair<int, int>> anchors;    // yolo: masked (w,h) pairs
     int classes = 0, row_offset = 0, rows = 0;

@@ -60,7 +60,7 @@ struct ConvArgs {
     int Ho = 0, Wo = 0, Cout = 0;
     float* out = nullptr;       int64_t out_ldc = 0; int out_coff = 0;
     const float* res = nullptr; int64_t res_ldc = 0; int res_coff = 0;   // fused shortcut
-    int leaky = 0;
+    int leaky = 0;                              // activation code: 0 linear, 1 leaky(0.1), 2 SiLU (apply_act)
     DecodeArgs dec;
     // split-precision path (conv_igemm_f16s3): pre-split, pre-scaled f16 weight planes [Npad][Kpad]
     // Weight planes are K-chunk major: [Kpad/32 chunks][Npad rows][32 halves], chunk kc = (c/32)*kh*kw + tap.  One (chunk, tap)
@@ -103,6 +103,15 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l, flo
     const float vc = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
     h = (_Float16)vc;
     l = (_Float16)(vc - (float)h);
+}
+// Activation of a conv epilogue: 0 linear, 1 leaky(0.1) (src/darknet.py:497-501), 2 SiLU x * sigmoid(x) (cfg extension).
+// Exact-fp32 kernels and the stems only: the split-f16 epilogues know linear / leaky (a SiLU there measured 2.5 % on the
+// whole YOLOv3 forward — the compiler evaluates both arms per value — so split plans reject activation=silu and
+// precision="auto" runs such cfgs on the fp32 kernels).
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : v * 0.1f;
+    if (act == 2) return v / (1.0f + expf(-v));
+    return v;
 }
 __device__ __forceinline__ void split_overflow_report(int32_t* flag, float amax) {
     if (flag && !(amax <= F16_MAX)) atomicOr(flag, 1);        // also true for NaN
@@ -175,7 +184,8 @@ int launch_prep_image(const unsigned char* img, int h, int w, int bgr, int inp_d
 int launch_pack_input(const float* x_nchw, int B, int C, int H, int W, float* out_nhwc, int Cp, hipStream_t s);
 int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
 int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s);
-int launch_maxpool(const View& in, const View& out, int B, int size, int stride, hipStream_t s);
+int launch_maxpool(const View& in, const View& out, int B, int size, int stride, int pad, hipStream_t s);   // pad > 0: symmetric -inf padding
+int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_t s);
 int launch_copy(const View& in, const View& out, int B, hipStream_t s);
 int launch_view_to_nchw(const View& in, int B, float* out_nchw, hipStream_t s);
 // strided decode: raw element (b, ch, y, x) at raw[b*sb + ch*sc + y*sy + x*sx]

@@ -139,8 +139,13 @@ class Darknet(nn.Module):
                     m.add_module("batch_norm_%d" % i, nn.BatchNorm2d(L.cout))
                 if L.leaky:
                     m.add_module("leaky_%d" % i, nn.LeakyReLU(0.1, inplace=True))
+                elif L.silu:                                   # cfg extension (activation=silu)
+                    m.add_module("silu_%d" % i, nn.SiLU(inplace=True))
             elif L.type == "upsample":
-                m.add_module("upsample_%d" % i, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+                if L.nearest:                                  # cfg extension (mode=nearest)
+                    m.add_module("upsample_%d" % i, nn.Upsample(scale_factor=2, mode="nearest"))
+                else:
+                    m.add_module("upsample_%d" % i, nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
             elif L.type == "route":
                 if isinstance(blk["layers"], str):
                     blk["layers"] = blk["layers"].split(",")        # the reference splits in place
@@ -148,7 +153,10 @@ class Darknet(nn.Module):
             elif L.type == "shortcut":
                 m.add_module("shortcut_%d" % i, EmptyLayer())
             elif L.type == "maxpool":
-                m.add_module("maxpool_%d" % i, nn.MaxPool2d(L.size, L.stride) if L.stride != 1 else MaxPoolStride1(L.size))
+                if L.pool_pad:                                 # cfg extension (symmetric=1)
+                    m.add_module("maxpool_%d" % i, nn.MaxPool2d(L.size, L.stride, L.pool_pad))
+                else:
+                    m.add_module("maxpool_%d" % i, nn.MaxPool2d(L.size, L.stride) if L.stride != 1 else MaxPoolStride1(L.size))
             elif L.type == "yolo":
                 m.add_module("Detection_%d" % i, DetectionLayer([tuple(a) for a in L.anchors]))
             module_list.append(m)

@@ -74,6 +74,34 @@ def test_native_plan_matches_python_ir(net, res):
     _ffi.lib().rtod_plan_destroy(h)
 
 
+def test_cfg_extensions_parse_identically_on_both_sides():
+    """activation=silu, [maxpool] symmetric=1, [upsample] mode=nearest (YOLOv5-style blocks, not reference grammar): the
+    native planner and the Python IR agree on shapes and flags; the plan needs no stand-alone add / copy / decode."""
+    text = cfgs.v5_style_mini_cfg()
+    for res in (128, 224):
+        rc, h = _plan(text, res)
+        assert rc == 0, _ffi.last_error()
+        d = _describe(h)
+        ir = build_ir(parse_cfg_text(text), res)
+        assert d["n_weight_floats"] == ir.n_weights and d["conv_flops"] == ir.conv_flops and d["total_rows"] == ir.total_rows
+        for L, D in zip(ir.layers, d["layers"]):
+            assert (L.type, L.cin, L.cout, L.hout, L.wout, L.size, L.stride, L.pad) == (D["type"], D["cin"], D["cout"], D["hout"], D["wout"], D["size"], D["stride"], D["pad"])
+            assert (2 if L.silu else 1 if L.leaky else 0, L.nearest, L.pool_pad) == (D["act"], D["nearest"], D["pool_pad"])
+        info = _ffi.PlanInfo()
+        assert _ffi.lib().rtod_plan_get_info(h, C.byref(info)) == 0
+        kinds = []
+        for i in range(info.n_launches):
+            li = _ffi.LaunchInfo()
+            assert _ffi.lib().rtod_plan_get_launch(h, i, C.byref(li)) == 0
+            kinds.append(li.kind)
+        assert 3 not in kinds and 5 not in kinds and 6 not in kinds
+        assert _ffi.lib().rtod_plan_set_precision(h, 1) != 0 and "silu" in _ffi.last_error()   # SiLU: exact-fp32 kernels only
+        _ffi.lib().rtod_plan_destroy(h)
+        rc, h = _plan(cfgs.v5_style_mini_cfg(act="leaky"), res)
+        assert rc == 0 and _ffi.lib().rtod_plan_set_precision(h, 1) == 0, _ffi.last_error()    # pools / nearest upsample: both formats
+        _ffi.lib().rtod_plan_destroy(h)
+
+
 def test_buffer_plan_has_no_live_overlap():
     rc, h = _plan(cfgs.yolov3_cfg(), 608)
     assert rc == 0
