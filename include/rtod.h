@@ -93,7 +93,10 @@ int rtod_plan_launch_kernel_name(const rtod_plan* plan, int index, char* buf, si
  *   1  split-precision f16 MFMA: a*w ~= ah*wh + ah*wl + al*wh with fp32 accumulation (22-bit
  *      operands, error ~2x fp32 per layer), 16x the MFMA rate per product.  Activations live in
  *      HBM as f16 hi/lo planes (x8 pre-scaled): needs |activation| < 8188, every conv after the
- *      stem with Cin % 32 == 0, no maxpool / stand-alone shortcut; otherwise RTOD_E_CFG. */
+ *      stem with Cin % 32 == 0, no stand-alone shortcut / copy / decode launch, no activation=silu; otherwise RTOD_E_CFG.
+ * cfg grammar: the reference's (src/darknet.py:412-603) plus three extension keys for YOLOv5-style blocks (detect.py:255-285
+ * fetches that model from the network; only its building blocks exist here): [convolutional] activation=silu,
+ * [maxpool] symmetric=1 (-inf padding of (size-1)/2 per side), [upsample] mode=nearest. */
 int rtod_plan_set_precision(rtod_plan* plan, int mode);
 /* Plan options (call before rtod_plan_load_weights; re-plans buffers and launches).  All default to 1 / -1:
  *   "fuse_pointwise"    1x1 conv in the previous conv's epilogue where one workgroup holds all its input channels
@@ -103,6 +106,11 @@ int rtod_plan_set_precision(rtod_plan* plan, int mode);
  *   "stem_kernel"       dedicated NCHW-reading kernel for layer 0; 0: input pack + generic conv
  *   "band_kernel"       LDS-band kernel for 3x3 stride-1 layers; 0: generic implicit GEMM
  *   "ring_kernel"       persistent LDS-DMA ring tiles among the autotune candidates (bit-identical to the generic tiles)
+ *   "patch_kernel"      2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers (bit-identical)
+ *   "stem2_kernel"      layers 0-2 of Darknet-53 in one kernel (conv_stem2_f16s3.hip, bit-identical); 0: stand-alone kernels
+ *   "pw_kernel"         (default 0) streaming kernel for the stand-alone 1x1 layers
+ *   "k_slices"          exact-fp32 plans: deep small-grid layers summed in K slices (conv_igemm_f32.hip); 0: one chain
+ *   "k_slice_workgroups" ... one workgroup per slice when the grid is small; 0: always inside the workgroup (same bits)
  *   "force_f16s3_variant" / "force_f32_variant"   >= 0: one tile variant for every conv (tests, A/B runs)
  * Options that leave a cfg inexpressible in the split-f16 format return RTOD_E_CFG when precision is 1. */
 int rtod_plan_set_option(rtod_plan* plan, const char* name, int value);
