@@ -226,6 +226,144 @@ void conv_patch_f16s3_kernel(const ConvArgs a, const int tiles_x, const int tile
     patch_wait_vmcnt<0>();                                       // trailing (out-of-range) pieces: nothing may be in flight at exit
 }
 
+// ---- Weights-resident variant (mode PATCH_WRES_MODE): Cin = 32, Cout = 64 (YOLOv3's layer 3, 304x304 at 608x608).
+// With K = 288 a tile is nine steps, and the streamed-weight kernel above moves 73 KB of weights per 128-pixel tile through
+// L2 -> LDS: 5 776 tiles x 73 KB = 422 MB per launch, as much as the layer's activations.  Here the nine taps' weights stay
+// in LDS for the lifetime of the persistent workgroup (one per CU): per tile one barrier, the next tile's patch by LDS-DMA
+// under the nine taps, tap t + 1's fragments read while tap t's twelve MFMAs run (conv_stem2_f16s3.hip's tap loop, which
+// runs at the MFMA rate).  Same K order and product order as every other tile of the layer: bit-identical.
+constexpr int PW_W1 = 9 * 64 * 64;                                      // one plane of the resident weights: [tap][64 rows][64 B]
+constexpr int PW_LDS = 4 * PT_PLANE + 2 * PW_W1;
+template <int EPI>
+__global__ __launch_bounds__(512, 2)
+void conv_patch_wres_f16s3_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+    constexpr int NWN = 2, NW = 8, WM = 32, WN = 32, TM = 2, TN = 2, PATCH = 2 * PT_PLANE;
+    constexpr int NPIECE = PT_PROWS / 16, PPW = (NPIECE + NW - 1) / NW;
+    static_assert(EPI == EPI_SPLIT || EPI == EPI_SPLIT_RES, "patch kernel epilogues");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const w1 = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n_tiles = a.B * tiles_y * tiles_x;
+    const unsigned PS = (unsigned)a.in_ldc * 4u, lo_plane = (unsigned)a.in_ldc * 2u;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    auto tile_of = [&](int t, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = t & 7;
+        int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+        x0 = (u % tiles_x) * PT_TW; u /= tiles_x;
+        y0 = (u % tiles_y) * PT_TH; b = u / tiles_y;
+    };
+
+    // ---- once: the nine taps' weights -> LDS (rows in the transposed product's channel order, chunk swizzle on the source side)
+    const int lrow = lane >> 2;
+    {
+        const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
+        for (int p = wave; p < 9 * 4; p += NW) {                         // (tap, 16-row block): one hi + one lo piece each
+            const int tap = p >> 2, rb = p & 3;
+            const int rho = rb * 16 + lrow;
+            const int ch = (lane & 3) ^ ((rho >> 1) & 3);
+            const unsigned vo = (unsigned)(tr_chan_of_row(rho) * 32 + ch * 8) * 2u;      // planes are [chunk*9 + tap][Npad][32], Cin = 32: chunk 0
+            const unsigned koff = (unsigned)tap * (unsigned)a.Npad * 64u;
+            const unsigned l = lds0 + 2u * PATCH + (unsigned)(tap * 64 * 64 + rb * 1024);
+            patch_dma_pair(rs_wh, rs_wl, vo, koff, koff, l, l + PW_W1);
+        }
+    }
+    // ---- patch loader (as above, one chunk)
+    int pc_piece[PPW], pdy[PPW], pdx[PPW]; unsigned pchunk[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        pc_piece[j] = (wave + j * NW) % NPIECE;
+        const int q = pc_piece[j] * 16 + lrow;
+        const int py = q / PT_PC, px = q - py * PT_PC;
+        pdy[j] = q < PT_PE ? py - 1 : -(1 << 20);
+        pdx[j] = px - 1;
+        pchunk[j] = (unsigned)(((lane & 3) ^ ((q >> 1) & 3)) * 8) * 2u;
+    }
+    auto patch_issue = [&](int pt, int pbuf) __attribute__((always_inline)) {
+        int b, y0, x0;
+        tile_of(pt < n_tiles ? pt : 0, b, y0, x0);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int iy = y0 + pdy[j], ix = x0 + pdx[j];
+            const bool ok = pt < n_tiles && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const unsigned vo = ok ? (unsigned)((b * a.Hi + iy) * a.Wi + ix) * PS + (unsigned)a.in_coff * 2u + pchunk[j] : OOB;
+            const unsigned l = lds0 + (unsigned)pbuf * PATCH + (unsigned)pc_piece[j] * 1024u;
+            patch_dma_pair(rs_a, rs_a, vo, 0u, lo_plane, l, l + PT_PLANE);
+        }
+    };
+
+    // ---- consumer state: wave (wm, wn) owns output rows 2 wm, 2 wm + 1 of the tile and channels 32 wn .. 32 wn + 31
+    const int wm = wave / NWN, wn = wave - wm * NWN;
+    const int lr = lane & 15, lh = lane >> 4;
+    const int w_lane = ((wn * 2) * 16 + lr) * 64 + ((lh ^ ((lr >> 1) & 3)) << 4);
+    int a_base[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_base[i] = (wm * TM + i) * PT_PC + lr;
+
+    patch_issue(blockIdx.x, 0);
+    patch_wait_vmcnt<0>();                                               // weights and the first patch: this wave's pieces
+    int pbuf = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int tb, y0, x0;
+        tile_of(tile, tb, y0, x0);
+        __builtin_amdgcn_s_barrier();                                    // everybody's pieces of this tile's patch landed; the other buffer is free
+        patch_issue(tile + (int)gridDim.x, pbuf ^ 1);                    // next tile's patch: in flight under the nine taps
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* pp = smem + pbuf * PATCH;
+        f16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+        auto load_tap = [&](int tap, int buf) __attribute__((always_inline)) {
+            const int shift = (tap / 3) * PT_PC + (tap % 3);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int q = a_base[i] + shift;
+                const int o = q * 64 + ((lh ^ ((q >> 1) & 3)) << 4);
+                fah[buf][i] = *reinterpret_cast<const f16x8*>(pp + o);
+                fal[buf][i] = *reinterpret_cast<const f16x8*>(pp + PT_PLANE + o);
+            }
+            const unsigned char* wp = w1 + tap * 64 * 64 + w_lane;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fbh[buf][j] = *reinterpret_cast<const f16x8*>(wp + j * 1024);
+                fbl[buf][j] = *reinterpret_cast<const f16x8*>(wp + PW_W1 + j * 1024);
+            }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < 9) load_tap(tap + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[cur][j], fal[cur][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[cur][j], fah[cur][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[cur][j], fah[cur][i], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        patch_wait_vmcnt<0>();                                           // this wave's pieces of the next patch (issued nine taps ago) and older stores
+        int mrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int oy = y0 + wm * TM + i, ox = x0 + lr;
+            mrow[i] = (oy < a.Ho && ox < a.Wo) ? (tb * a.Ho + oy) * a.Wo + ox : -1;
+        }
+        conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES>(a, acc, nullptr, mrow, wn * WN, tid, lh);
+        pbuf ^= 1;
+    }
+    patch_wait_vmcnt<0>();
+}
+
 bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && cout % 8 == 0;
 }
@@ -235,15 +373,21 @@ bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout) {
 #define RTOD_PATCH_TILES(X) X(0, 64, 4, 2, 4, 4) X(1, 128, 4, 2, 3, 2) X(2, 64, 4, 2, 3, 4) X(3, 128, 4, 2, 4, 2)
 
 #define RTOD_X_INFO(mode, bn, nwm, nwn, st, minw) {PT_BM, bn, "conv_patch_f16s3<8x16x" #bn "," #nwm "x" #nwn ",s" #st ">"},
-static const ConvVariantInfo kPatchModes[PATCH_MODES] = { RTOD_PATCH_TILES(RTOD_X_INFO) };
+static const ConvVariantInfo kPatchModes[PATCH_MODES] = { RTOD_PATCH_TILES(RTOD_X_INFO) {PT_BM, 64, "conv_patch_f16s3<8x16x64,4x2,weights resident>"} };
 #undef RTOD_X_INFO
+static_assert(PATCH_WRES_MODE == PATCH_MODES - 1, "the weights-resident mode is the last patch mode");
 const ConvVariantInfo& conv_patch_mode_info(int mode) { return kPatchModes[mode < 0 || mode >= PATCH_MODES ? 0 : mode]; }
+bool conv_patch_mode_valid(int mode, int cin, int cout) {
+    if (mode < 0 || mode >= PATCH_MODES) return false;
+    return mode != PATCH_WRES_MODE || (cin == 32 && cout == 64);
+}
 
 int conv_patch_kernel_name(int mode, int epi, char* buf, size_t len) {
 #define RTOD_X_NAME(m, bn, nwm, nwn, st, minw) \
     if (mode == m) return snprintf(buf, len, "void rtod::conv_patch_f16s3_kernel<" #bn ", " #nwm ", " #nwn ", " #st ", " #minw ", %d>(rtod::ConvArgs, int, int, int)", epi);
     RTOD_PATCH_TILES(RTOD_X_NAME)
 #undef RTOD_X_NAME
+    if (mode == PATCH_WRES_MODE) return snprintf(buf, len, "void rtod::conv_patch_wres_f16s3_kernel<%d>(rtod::ConvArgs, int, int)", epi);
     return -1;
 }
 
@@ -282,6 +426,29 @@ int launch_conv_patch_f16s3(const ConvArgs& a, int mode, hipStream_t s) {
     if (a.in_ldc % 8 || a.in_coff % 8 || a.out_ldc % 8 || a.out_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin) { set_error("launch_conv_patch: bad view / K"); return RTOD_E_ARG; }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_patch: buffer extents"); return RTOD_E_ARG; }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_patch: input view exceeds its buffer"); return RTOD_E_ARG; }
+    if (mode == PATCH_WRES_MODE) {
+        if (a.Cin != 32 || a.Cout != 64 || a.Npad < 64) { set_error("launch_conv_patch: the weights-resident tile needs Cin = 32, Cout = 64"); return RTOD_E_ARG; }
+        const int tiles_x = (a.Wo + PT_TW - 1) / PT_TW, tiles_y = (a.Ho + PT_TH - 1) / PT_TH;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return hip_fail(hipGetLastError(), "conv_patch_f16s3 device query");
+        const int64_t tiles = (int64_t)a.B * tiles_x * tiles_y;
+        if (tiles >= (1ll << 30)) { set_error("launch_conv_patch: too many tiles"); return RTOD_E_ARG; }
+        const int grid = (int)(tiles < cus ? tiles : cus);
+        auto k_res = conv_patch_wres_f16s3_kernel<EPI_SPLIT_RES>;
+        auto k_plain = conv_patch_wres_f16s3_kernel<EPI_SPLIT>;
+        static std::atomic<unsigned long long> attr_done{0};
+        if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return hip_fail(hipGetLastError(), "conv_patch_f16s3 LDS attribute");
+            attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+        }
+        static_assert(PW_LDS <= 160 * 1024, "LDS budget");
+        if (a.res) hipLaunchKernelGGL(k_res, dim3(grid), dim3(512), PW_LDS, s, a, tiles_x, tiles_y);
+        else hipLaunchKernelGGL(k_plain, dim3(grid), dim3(512), PW_LDS, s, a, tiles_x, tiles_y);
+        return hip_fail(hipGetLastError(), "conv_patch_wres_f16s3 launch");
+    }
     switch (mode) {
 #define RTOD_X_CASE(m, bn, nwm, nwn, st, minw) case m: return launch_patch<bn, nwm, nwn, st, minw>(a, s);
         RTOD_PATCH_TILES(RTOD_X_CASE)

@@ -887,6 +887,7 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
         if (!pw && opt_patch_kernel && conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && L.hout == L.hin && l.out_layer != -2)
             for (int m = 0; m < PATCH_MODES; ++m) {
                 if (conv_patch_mode_info(m).bn > L.cout && conv_patch_mode_info(m).bn > 64) continue;
+                if (!conv_patch_mode_valid(m, L.cin, L.cout)) continue;
                 cand.push_back(PATCH_VARIANT_BASE + m);
             }
         if (!pw && opt_ring_kernel)
@@ -965,7 +966,7 @@ int Plan::variant_for(const Launch& l, int batch) const {
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
         if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active())) return v;
         if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 &&
-            conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin) return v;
+            conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, FL.cin, FL.cout)) return v;
         const int g = choose_variant_f16s3(layers[l.layer], batch);
         if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;
         return g;

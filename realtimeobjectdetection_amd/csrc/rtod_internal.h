@@ -159,7 +159,9 @@ int launch_conv_stem2_f16s3(const float* x, int B, int H, int W, const _Float16*
                             int leaky0, const ConvArgs& c1, hipStream_t s);
 // 2-D tiled 3x3 stride-1 kernel with an LDS-resident input patch (conv_patch_f16s3.hip): for images too wide for the band
 // kernel; bit-identical to the generic / ring tiles, so its modes are further autotune candidates of those layers.
-constexpr int PATCH_MODES = 4;
+constexpr int PATCH_MODES = 5;
+constexpr int PATCH_WRES_MODE = 4;         // weights resident in LDS (Cin = 32, Cout = 64 only)
+bool conv_patch_mode_valid(int mode, int cin, int cout);
 constexpr int PATCH_VARIANT_BASE = 110;    // variant ids >= this: PATCH_VARIANT_BASE + mode
 bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout);
 const ConvVariantInfo& conv_patch_mode_info(int mode);
