@@ -21,9 +21,17 @@
 //     fragments + MFMAs.
 // K order and MFMA order are those of conv_igemm_f16s3.hip / conv_band_f16s3.hip (32-channel chunk outer, tap inner; per
 // chunk al*bh, ah*bl, ah*bh), so a layer gives the same bits on any tile of this kernel.
+// Measured and not kept (round 2): two k32 chunks per ring stage (one barrier per 64 channels; 64x128 / 64x64 / 128x64 tiles,
+// bit-identical) — 0.94-0.96 ms for the 36 1x1 layers of YOLOv3 against 0.83 for the same tiles with one chunk per stage:
+// the doubled stage costs the second workgroup per CU, which hides more latency than the halved barrier count saves.
+// Three workgroups per CU (64x64 with a 3-stage ring) or shallower rings on the other tiles: no change (0.84 vs 0.84).  With every
+// load and the epilogue switched off (RTOD_DIAG, tools/ablate_1x1.sh) these layers still take 14-18 of their 19-23 us: what a
+// step costs is issuing its LDS-DMA pieces (4-6 per wave and step at ~100-185 cycles each, MI355X_MICROARCH 'LDS-DMA piece issue
+// cost') against 288-384 cycles of MFMAs — tiles with more MFMA work per staged kilobyte are the lever, not the schedule.
 #include "conv_f16s3_common.h"
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 
 namespace rtod {
 
@@ -240,6 +248,9 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
         // epilogue: the slot just consumed is the only one the loader does not own (it is refilled after the next tile's
         // first barrier); the other STAGES-1 slots keep filling for the next tile meanwhile
+#ifdef RTOD_DIAG
+        if (a.dbg & 4) continue;                                 // timing experiment: no epilogue
+#endif
         if constexpr (TRANSPOSED) {
             // straight from the accumulators: no LDS, no barrier — the waves drift apart here and re-align at the next step
             int mrow[TM];
@@ -308,7 +319,8 @@ static int launch_ring(const ConvArgs& a, hipStream_t s) {
     return hip_fail(hipGetLastError(), "conv_ring_f16s3 launch");
 }
 
-int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s) {
+int launch_conv_ring_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
+    ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_ring: null pointer"); return RTOD_E_ARG; }
     if (a.Cin % HBK || a.in_ldc % 8 || a.in_coff % 8 || a.Kpad % HBK || a.K != a.Kpad || a.K != a.kh * a.kw * a.Cin) {
         set_error("launch_conv_ring: needs Cin %% 32 == 0 and 8-channel aligned views (Cin=%d ldc=%ld coff=%d K=%d Kpad=%d)", a.Cin, (long)a.in_ldc, a.in_coff, a.K, a.Kpad);
@@ -317,6 +329,13 @@ int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s) {
     if (a.B <= 0 || a.Ho <= 0 || a.Wo <= 0 || a.Cout <= 0) { set_error("launch_conv_ring: empty shape"); return RTOD_E_ARG; }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_ring: buffer extents"); return RTOD_E_ARG; }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_ring: input view exceeds its buffer"); return RTOD_E_ARG; }
+#ifdef RTOD_DIAG
+    // diagnostic build only: zero-extent descriptors drop the loads of one operand (DMA pieces then write zeros), bit 4 the epilogue
+    static const int dbg_zero = getenv("RTOD_DBG_ZERO") ? atoi(getenv("RTOD_DBG_ZERO")) : 0;
+    if (dbg_zero & 1) a.in_bytes = 1;
+    if (dbg_zero & 2) a.w_bytes = 1;
+    a.dbg = dbg_zero;
+#endif
     switch (mode) {
 #define RTOD_X_CASE(m, bm, bn, nwm, nwn, st, minw, wpc) case m: return launch_ring<bm, bn, nwm, nwn, st, minw, wpc>(a, s);
         RTOD_RING_TILES(RTOD_X_CASE)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # time of the 1x1 layer groups under every forced tile variant (autotune off), one box
 out=$1; mkdir -p $out
-for v in auto 0 1 2 3 6 7 9 10 11 70 71 72 73 74 75 76 77; do
+for v in ${SWEEP_V:-auto 0 1 2 3 6 7 9 10 11 70 71 72 73 74 75 76 77}; do
   if [ $v = auto ]; then args=""; else args="autotune=0 force_f16s3_variant=$v"; fi
   timeout -k 10 120 python tools/exp_layers.py $out/v$v.json 608 8 $args > /dev/null 2>&1 || { echo "v$v failed"; continue; }
   python - <<PY
