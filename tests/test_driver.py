@@ -118,6 +118,20 @@ def test_detector_driver_end_to_end(tmp_path):
             rows = np.array(saved[name], dtype=np.float32)
             assert rows.shape[1] == 8 and np.all(rows[:, 0] == idx)
             assert np.allclose(rows[:, 1:], r.cpu().numpy()[:, 1:], rtol=0, atol=0)   # frames are batch-independent: identical
+    # ... and with the ORACLE pipeline on the same preprocessed frames (the reference's CPU arithmetic: RefDarknet forward +
+    # write_results; prep_image has its own oracle test above): same detections up to threshold-adjacent flips
+    from oracle import darknet_ref as O
+    from detcompare import assert_detections_equivalent
+    ref = O.RefDarknet(cfgs.yolov3_tiny_cfg(), 416)
+    ref.load_weight_stream(synth.synth_weights(ir))
+    for idx, name in enumerate(sorted(arrays)):
+        x = prep_image(arrays[name], 416, "RGB").cpu()
+        with torch.no_grad():
+            want = O.write_results(ref.forward(x), 80, 0.5, 0.5)
+        got = np.array(saved[name], dtype=np.float32).reshape(-1, 8) if saved[name] != 0 else np.zeros((0, 8), np.float32)
+        got[:, 0] = 0
+        wrows = np.zeros((0, 8), np.float32) if isinstance(want, int) else want.numpy()
+        assert_detections_equivalent(got, wrows, 0.5, 0.5)
 
 
 def test_shipped_params_json_resolves_or_fails_with_instructions(tmp_path, monkeypatch, capsys):
