@@ -64,6 +64,7 @@ __device__ __forceinline__ int band_swz(int row) { return (row >> 1) & 3; }
 #ifdef RTOD_STAMPS
 constexpr int STAMP_SLOTS = 8, STAMP_BLOCKS = 128, STAMP_WAVES = 16;
 __device__ unsigned long long g_band_stamps[STAMP_BLOCKS * STAMP_WAVES * (STAMP_SLOTS + 1)];
+__device__ unsigned long long g_band_real[STAMP_BLOCKS * STAMP_WAVES];     // s_memrealtime ticks (100 MHz) over the same span: the clock the chip held
 #define RTOD_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ts_[i] += tn_ - tprev_; tprev_ = tn_; }
 #else
 #define RTOD_STAMP(i)
@@ -296,6 +297,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     unsigned long long ts_[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart_ = tprev_;
+    const unsigned long long rstart_ = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- prologue.  Issue order (vmcnt is in-order): band(0), B0, B1 | band written, B0 staged | B2, band(1)
     gload_band(0);
@@ -365,6 +367,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         unsigned long long* o = g_band_stamps + (blockIdx.x * STAMP_WAVES + (threadIdx.x >> 6)) * (STAMP_SLOTS + 1);
         for (int i = 0; i < STAMP_SLOTS; ++i) o[i] = ts_[i];
         o[STAMP_SLOTS] = tprev_ - tstart_;
+        g_band_real[blockIdx.x * STAMP_WAVES + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime() - rstart_;
     }
 #endif
 }
@@ -409,6 +412,12 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
                     sum[i] += (double)h[(b * STAMP_WAVES + w) * (STAMP_SLOTS + 1) + i];
                 fprintf(stderr, "[stamps] band<%d,%d,%dx%d,k%d> W=%d Cin=%d Cout=%d tiles=%d steps=%d | cycles/wave:", BM, BN, NWM, NWN, KG, a.Wi, a.Cin, a.Cout, gm * gn, 9 * a.Cin / 32 / KG);
                 for (int i = 0; i <= STAMP_SLOTS; ++i) fprintf(stderr, " %s%.0f", i == STAMP_SLOTS ? "total=" : "", sum[i] / (nb * nw));
+                static unsigned long long hr[STAMP_BLOCKS * STAMP_WAVES];
+                if (hipMemcpyFromSymbol(hr, HIP_SYMBOL(g_band_real), sizeof(hr)) == hipSuccess) {
+                    double real = 0;
+                    for (int b = 0; b < nb; ++b) for (int w = 0; w < nw; ++w) real += (double)hr[b * STAMP_WAVES + w];
+                    if (real > 0) fprintf(stderr, " | clock %.0f MHz", sum[STAMP_SLOTS] / real * 100.0);     // s_memtime / s_memrealtime x 100 MHz
+                }
                 fprintf(stderr, "\n");
                 ++printed;
             }
