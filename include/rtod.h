@@ -109,6 +109,7 @@ int rtod_plan_set_precision(rtod_plan* plan, int mode);
  *   "patch_kernel"      2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers (bit-identical)
  *   "stem2_kernel"      layers 0-2 of Darknet-53 in one kernel (conv_stem2_f16s3.hip, bit-identical); 0: stand-alone kernels
  *   "pw_kernel"         (default 0) streaming kernel for the stand-alone 1x1 layers
+ *   "bn_batch_stats"    (default 0) exact-fp32 plans: BatchNorm on batch statistics instead of the folded running statistics
  *   "k_slices"          exact-fp32 plans: deep small-grid layers summed in K slices (conv_igemm_f32.hip); 0: one chain
  *   "k_slice_workgroups" ... one workgroup per slice when the grid is small; 0: always inside the workgroup (same bits)
  *   "force_f16s3_variant" / "force_f32_variant"   >= 0: one tile variant for every conv (tests, A/B runs)
@@ -151,6 +152,11 @@ int rtod_plan_set_keep_all_layers(rtod_plan* plan, int keep);
  * [batch,C,H,W] after a forward; enqueues on stream. */
 int rtod_plan_layer_shape(const rtod_plan* plan, int layer, int* c, int* h, int* w);
 int rtod_plan_read_layer(rtod_plan* plan, int layer, int batch, float* out_dev_nchw, void* stream);
+/* Plans with option "bn_batch_stats" = 1 (exact fp32 only) run BatchNorm the way the reference's callers do: never calling
+ * .eval(), nn.BatchNorm2d normalises with the statistics of the batch (src/darknet.py:493-495, detect.py:185-194; SURVEY.md
+ * F2).  Per-channel mean and BIASED variance of a conv layer's last forward (host doubles; synchronises `stream`): what the
+ * host class needs to update running_mean / running_var like torch does (momentum 0.1, unbiased variance). */
+int rtod_plan_bn_batch_stats(rtod_plan* plan, int layer, double* mean_host, double* var_host, int channels, void* stream);
 
 /* replaces predict_transform                                 src/util.py:175-239
  * raw_dev [batch, A*attrs, G, G] NCHW -> out_dev [batch, G*G*A, attrs]; anchors = A (w,h) pairs

@@ -61,8 +61,10 @@ class RefDarknet:
         return p
 
     # -- forward ---------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, keep_layers=False):
-        """``x`` float32 ``[B,3,H,W]`` -> ``[B,N,5+C]`` (eval-mode BN)."""
+    def forward(self, x: torch.Tensor, keep_layers=False, batch_stats=False):
+        """``x`` float32 ``[B,3,H,W]`` -> ``[B,N,5+C]``.  BatchNorm: running statistics (eval, the canonical mode) or, with
+        ``batch_stats``, the statistics of the batch — what the reference's callers run without .eval() (SURVEY.md F2);
+        the running buffers are not updated here."""
         outputs = {}
         detections = None
         for L in self.ir.layers:
@@ -71,8 +73,11 @@ class RefDarknet:
                 p = self.params[i]
                 x = F.conv2d(x, p["weight"], p.get("bias"), L.stride, L.pad)
                 if L.bn:
-                    x = F.batch_norm(x, p["mean"], p["var"], p["gamma"], p["beta"],
-                                     training=False, momentum=0.1, eps=1e-5)
+                    if batch_stats:
+                        x = F.batch_norm(x, None, None, p["gamma"], p["beta"], training=True, momentum=0.1, eps=1e-5)
+                    else:
+                        x = F.batch_norm(x, p["mean"], p["var"], p["gamma"], p["beta"],
+                                         training=False, momentum=0.1, eps=1e-5)
                 if L.leaky:
                     x = F.leaky_relu(x, 0.1)
                 elif L.silu:                       # cfg extension, not reference behaviour: checked against torch's own op

@@ -311,6 +311,83 @@ int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Batch-statistics BatchNorm ("as run" by the reference: detect.py never calls .eval(), so nn.BatchNorm2d normalises
+// with the statistics of the batch, src/darknet.py:493-495).  Optional parity mode of the exact-fp32 plans
+// (plan option bn_batch_stats): the conv writes its raw sums, bn_stats_kernel reduces per-channel mean and biased
+// variance over (B, H, W) in double precision (PyTorch's CPU kernels accumulate float statistics in double), then
+// bn_apply_kernel normalises, applies the activation and the fused shortcut in place.
+// stats layout: [sstride] mean, [sstride] biased variance (doubles).
+__global__ __launch_bounds__(256)
+void bn_stats_kernel(View x, int B, double* __restrict__ stats, int sstride) {
+    // one workgroup per group of 4 channels; threads stride over the pixels (deterministic: fixed partition, ordered tree)
+    const int c = blockIdx.x * 4;
+    const int64_t npix = (int64_t)B * x.H * x.W;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int64_t p = threadIdx.x; p < npix; p += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x.base + x.coff + c + p * x.ldc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; q[e] += (double)v[e] * (double)v[e]; }
+    }
+    __shared__ double red[2][4][256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] = s[e]; red[1][e][threadIdx.x] = q[e]; }
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] += red[0][e][threadIdx.x + w]; red[1][e][threadIdx.x] += red[1][e][threadIdx.x + w]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4 && c + (int)threadIdx.x < x.C) {
+        const int e = threadIdx.x;
+        const double mean = red[0][e][0] / (double)npix;
+        double var = red[1][e][0] / (double)npix - mean * mean;
+        if (var < 0) var = 0;
+        stats[c + e] = mean;
+        stats[sstride + c + e] = var;
+    }
+}
+
+// y = (x - mean) / sqrt(var + eps) * gamma + beta, activation, + shortcut; x and y may be the same view.
+// bn: [gstride] beta, [gstride] gamma (the order of the .weights stream, src/darknet.py:356-376)
+__global__ void bn_apply_kernel(View x, View y, View res, int has_res, int B, const double* __restrict__ stats, int sstride,
+                                const float* __restrict__ bn, int gstride, int act) {
+    const int C4 = x.C / 4;
+    const int64_t total = (int64_t)B * x.H * x.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        const int64_t p = t / C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x.base + x.coff + c + p * x.ldc);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (has_res) r = *reinterpret_cast<const f32x4*>(res.base + res.coff + c + p * res.ldc);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double invstd = 1.0 / sqrt(stats[sstride + c + e] + 1e-5);
+            const float w = (float)(invstd * (double)bn[gstride + c + e]);                      // gamma / sqrt(var + eps)
+            const float b = (float)((double)bn[c + e] - stats[c + e] * invstd * (double)bn[gstride + c + e]);
+            float u = v[e] * w + b;
+            u = apply_act(u, act);
+            o[e] = has_res ? u + r[e] : u;
+        }
+        *reinterpret_cast<f32x4*>(y.base + y.coff + c + p * y.ldc) = o;
+    }
+}
+
+int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act, hipStream_t s) {
+    if (x.split || y.split || (res && res->split)) { set_error("bn_batch: exact-fp32 plans only"); return RTOD_E_ARG; }
+    if (!view_ok4(x) || !view_ok4(y) || x.C != y.C || x.H != y.H || x.W != y.W || !stats || !bn || gstride < x.C || sstride < x.C) { set_error("bn_batch: bad views"); return RTOD_E_ARG; }
+    if (res && (!view_ok4(*res) || res->C != x.C || res->H != x.H || res->W != x.W)) { set_error("bn_batch: bad shortcut view"); return RTOD_E_ARG; }
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(x.C / 4), dim3(256), 0, s, x, B, stats, sstride);
+    if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_stats launch");
+    const int64_t total = (int64_t)B * x.H * x.W * (x.C / 4);
+    View r = res ? *res : x;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, y, r, res ? 1 : 0, B, stats, sstride, bn, gstride, act);
+    return hip_fail(hipGetLastError(), "bn_apply launch");
+}
+
+// ---------------------------------------------------------------------------------------------
 // NHWC view -> dense NCHW (test/debug read-back of a layer output)
 __global__ void view_to_nchw_kernel(View in, int B, float* __restrict__ out) {
     const int64_t total = (int64_t)B * in.C * in.H * in.W;

@@ -218,6 +218,24 @@ int rtod_plan_read_layer(rtod_plan* plan, int layer, int batch, float* out_dev_n
     RTOD_GUARD_END
 }
 
+int rtod_plan_bn_batch_stats(rtod_plan* plan, int layer, double* mean_host, double* var_host, int channels, void* stream) {
+    RTOD_GUARD_BEGIN
+    if (!plan || !mean_host || !var_host || layer < 0 || layer >= (int)plan->p.layers.size()) { set_error("bn_batch_stats: bad args"); return RTOD_E_ARG; }
+    if (!plan->p.opt_bn_batch_stats || !plan->p.d_bn_stats) { set_error("bn_batch_stats: the plan does not run batch-statistics BatchNorm (option bn_batch_stats, weights loaded)"); return RTOD_E_STATE; }
+    for (const auto& pc : plan->p.convs) {
+        if (pc.layer != layer) continue;
+        if (pc.stats_off < 0 || channels != plan->p.layers[layer].cout) { set_error("bn_batch_stats: layer %d has no BatchNorm / %d channels", layer, plan->p.layers[layer].cout); return RTOD_E_ARG; }
+        RTOD_HIP(hipSetDevice(plan->p.device));
+        RTOD_HIP(hipStreamSynchronize((hipStream_t)stream));
+        RTOD_HIP(hipMemcpy(mean_host, plan->p.d_bn_stats + pc.stats_off, sizeof(double) * channels, hipMemcpyDeviceToHost));
+        RTOD_HIP(hipMemcpy(var_host, plan->p.d_bn_stats + pc.stats_off + pc.Npad, sizeof(double) * channels, hipMemcpyDeviceToHost));
+        return RTOD_OK;
+    }
+    set_error("bn_batch_stats: layer %d is not a convolution", layer);
+    return RTOD_E_ARG;
+    RTOD_GUARD_END
+}
+
 int rtod_predict_transform(const float* raw_dev, int batch, int attrs, int grid, int n_anchors, const float* anchors_wh,
                            int inp_dim, int train, float* out_dev, void* stream) {
     RTOD_GUARD_BEGIN

@@ -43,6 +43,7 @@ Plan::~Plan() {
     for (auto e : events) (void)hipEventDestroy(e);
     if (d_arena) (void)hipFree(d_arena);
     if (d_scratch) (void)hipFree(d_scratch);
+    if (d_bn_stats) (void)hipFree(d_bn_stats);
     if (d_weights) (void)hipFree(d_weights);
 }
 
@@ -294,6 +295,7 @@ int Plan::set_option(const char* name, int value) {
     else if (k == "ring_kernel") flag = &opt_ring_kernel;
     else if (k == "stem2_kernel") flag = &opt_stem2_kernel;
     else if (k == "k_slices") flag = &opt_k_slices;
+    else if (k == "bn_batch_stats") flag = &opt_bn_batch_stats;
     else if (k == "k_slice_workgroups") flag = &opt_k_slice_workgroups;
     else if (k == "patch_kernel") flag = &opt_patch_kernel;
     else if (k == "pw_kernel") flag = &opt_pw_kernel;
@@ -396,7 +398,7 @@ int Plan::plan_buffers() {
     if (layers[0].type != LT_CONV) { set_error("cfg: first layer must be convolutional"); return RTOD_E_CFG; }
     // dedicated stem kernel (reads NCHW directly) when layer 0 is a plain 3x3 / pad 1 conv with 32 or 64 filters
     const bool use_stem = layers[0].size == 3 && layers[0].pad == 1 && layers[0].cin == 3 && layers[0].cout % 32 == 0 &&
-                          layers[0].cout <= 64 && layers[0].fused_into < 0 && opt_stem_kernel;
+                          layers[0].cout <= 64 && layers[0].fused_into < 0 && opt_stem_kernel && !(opt_bn_batch_stats && layers[0].bn);
     if (!use_stem) { Launch l; l.kind = LK_PACK; l.layer = 0; launches.push_back(l); }
     for (auto& L : layers) {
         const int i = L.index;
@@ -505,6 +507,7 @@ bool Plan::uses_split(const Layer& L, int cin_p) const {
 }
 
 int Plan::check_split_supported() const {
+    if (opt_bn_batch_stats) { set_error("precision f16s3 unsupported with bn_batch_stats (batch-statistics BatchNorm runs on the exact-fp32 kernels)"); return RTOD_E_CFG; }
     // precision 1 keeps every activation in the split f16 format: every conv but the stem must read
     // 32-channel K-chunks, every shortcut / head must ride a conv epilogue, concats must be zero-copy
     for (const auto& l : launches) {
@@ -531,6 +534,11 @@ int Plan::check_split_supported() const {
 
 void Plan::layout_weights() {
     packed_floats = 0;
+    bn_stats_doubles = 0;
+    for (auto& pc : convs) {
+        pc.stats_off = -1;
+        if (opt_bn_batch_stats && layers[pc.layer].bn) { pc.stats_off = bn_stats_doubles; bn_stats_doubles += 2 * (int64_t)pc.Npad; }
+    }
     for (auto& pc : convs) {
         const Layer& L = layers[pc.layer];
         pc.split = uses_split(L, pc.cin_p);
@@ -562,6 +570,7 @@ void Plan::layout_weights() {
             pc.slice_chunks = (!opt_k_slices || L.hout * L.wout > 2704 || nkc < 8) ? 0 : nkc >= 32 ? 9 : nkc >= 16 ? 4 : 2;
         }
         pc.b_off = packed_floats; packed_floats += pc.Npad;
+        if (opt_bn_batch_stats && L.bn) { pc.bn_off = packed_floats; packed_floats += 2 * (int64_t)pc.Npad; }
         packed_floats = (packed_floats + 63) / 64 * 64;
     }
 }
@@ -652,7 +661,13 @@ int Plan::load_weights(const float* w, size_t n) {
         const int C = L.cout, cin = L.cin, k = L.size;
         std::vector<double> scale(C, 1.0);
         float* bias = packed.data() + pc.b_off;
-        if (L.bn) {
+        if (L.bn && opt_bn_batch_stats) {
+            // batch-statistics mode: the conv stays unfolded (no bias), beta / gamma go to the normalisation kernel; the
+            // stream's running mean / variance are not used (the reference only updates them as a side effect)
+            float* bnp = packed.data() + pc.bn_off;
+            for (int o = 0; o < C; ++o) { bias[o] = 0.f; bnp[o] = p[o]; bnp[pc.Npad + o] = p[C + o]; }
+            p += 4 * C;
+        } else if (L.bn) {
             const float *beta = p, *gamma = p + C, *mean = p + 2 * C, *var = p + 3 * C;
             for (int o = 0; o < C; ++o) {
                 // eval BatchNorm (x - mean) / sqrt(var + 1e-5) * gamma + beta folded into the conv
@@ -743,6 +758,10 @@ int Plan::load_weights(const float* w, size_t n) {
     if (!d_arena) {
         RTOD_HIP(hipMalloc((void**)&d_arena, sizeof(float) * (size_t)arena_floats));
         RTOD_HIP(hipMemset(d_arena, 0, sizeof(float) * (size_t)arena_floats));
+    }
+    if (opt_bn_batch_stats && !d_bn_stats && bn_stats_doubles > 0) {
+        RTOD_HIP(hipMalloc((void**)&d_bn_stats, sizeof(double) * (size_t)bn_stats_doubles));
+        RTOD_HIP(hipMemset(d_bn_stats, 0, sizeof(double) * (size_t)bn_stats_doubles));
     }
     if (!d_scratch) {
         bool any = false;
@@ -1028,6 +1047,15 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                     const int mode = f32_slice_mode(l, batch, v);
                     a.slice_chunks = mode ? pc.slice_chunks : 0;
                     if (mode == 2) { a.partial = d_scratch; a.partial_floats = scratch_floats; }
+                    if (opt_bn_batch_stats && L.bn) {            // raw conv, then statistics + normalise + activation + shortcut in place
+                        if (a.dec.enabled || a.out_split || !d_bn_stats || pc.stats_off < 0) { set_error("forward: layer %d: batch-statistics BatchNorm on an unsupported launch", l.layer); return RTOD_E_STATE; }
+                        a.leaky = 0; a.res = nullptr;
+                        rc = launch_conv(a, v, s);
+                        if (rc) return rc;
+                        const View o = view_of(l.out_layer);
+                        View r; if (l.in2_layer >= 0) r = view_of(l.in2_layer);
+                        rc = launch_bn_batch(o, o, l.in2_layer >= 0 ? &r : nullptr, batch, d_bn_stats + pc.stats_off, pc.Npad, d_weights + pc.bn_off, pc.Npad, L.act, s);
+                    } else
                     rc = launch_conv(a, v, s);
                 }
                 else if (li == 1 && stem2_active()) {                  // stem + this conv (+ its hosted 1x1) in one kernel

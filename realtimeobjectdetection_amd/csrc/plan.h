@@ -66,6 +66,8 @@ struct PackedConv {
     bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
     bool pw = false;                  // runs on conv_pw_f16s3 (stand-alone 1x1 conv, no residual / decode epilogue)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
+    int64_t stats_off = -1;           // batch-statistics BatchNorm plans: this layer's [Npad] mean, [Npad] variance in Plan::d_bn_stats (doubles)
+    int64_t bn_off = 0;               // batch-statistics BatchNorm plans: [Npad] beta, [Npad] gamma (the conv itself is packed unfolded)
     int slice_chunks = 0;             // exact-fp32 panels: K summed in slices of this many 32-wide chunks (0: one chain), conv_igemm_f32.hip
 };
 
@@ -82,6 +84,8 @@ struct Plan {
     int64_t arena_floats = 0, packed_floats = 0;
     float* d_arena = nullptr;
     float* d_weights = nullptr;
+    double* d_bn_stats = nullptr;     // batch-statistics BatchNorm: per-channel mean / biased variance of every BN layer's last forward
+    int64_t bn_stats_doubles = 0;
     float* d_scratch = nullptr;       // exact-fp32 plans: slice panels of the one-workgroup-per-K-slice schedule
     int64_t scratch_floats = 0;
     bool weights_loaded = false;
@@ -95,6 +99,7 @@ struct Plan {
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
     bool opt_pw_kernel = false;       // streaming kernel for the stand-alone 1x1 layers it supports (measured slower than the LDS-tiled kernels on the
                                       // pixel-major activation layout: 64-byte half-line loads; kept as an option)
+    bool opt_bn_batch_stats = false;  // exact-fp32 plans: BatchNorm on the statistics of the batch (what the reference runs: no .eval()), not folded
     bool opt_k_slices = true;         // exact-fp32 kernels: deep small-grid layers summed in K slices (own workgroups when the grid is small)
     bool opt_k_slice_workgroups = true;   // ... (off: always the in-workgroup schedule — same bits; A/B and tests)
     bool opt_stem2_kernel = true;     // stem + layer 1 (+ hosted 1x1) in one kernel when the cfg starts like Darknet-53 (split-f16 plans)

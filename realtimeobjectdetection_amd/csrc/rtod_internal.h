@@ -188,6 +188,8 @@ int launch_upsample2x(const View& in, const View& out, int B, hipStream_t s);
 int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t s);
 int launch_maxpool(const View& in, const View& out, int B, int size, int stride, int pad, hipStream_t s);   // pad > 0: symmetric -inf padding
 int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_t s);
+// batch-statistics BatchNorm (+ activation + shortcut) over a conv's raw output, in place (aux_kernels.hip); stats: 2*C doubles of scratch
+int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act, hipStream_t s);
 int launch_copy(const View& in, const View& out, int B, hipStream_t s);
 int launch_view_to_nchw(const View& in, int B, float* out_nchw, hipStream_t s);
 // strided decode: raw element (b, ch, y, x) at raw[b*sb + ch*sc + y*sy + x*sx]

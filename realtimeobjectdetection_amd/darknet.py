@@ -12,11 +12,11 @@ Everything numeric happens in hand-written HIP kernels behind the C ABI (include
 ``.parameters()`` / ``.cuda()`` keep working; PyTorch executes none of the network.  There is no
 CPU fallback: a non-CUDA input or a missing librtod.so raises.
 
-BatchNorm runs with running statistics (``.eval()`` semantics) folded into the convolutions — the
-canonical mode of SURVEY.md F2.  The reference's callers never call ``.eval()``, so there BN uses
-batch statistics (frames of a batch influence each other); that mode is not implemented and
-``forward`` refuses to run while ``self.training`` is set unless ``bn_running_stats_in_train`` is
-enabled explicitly.
+BatchNorm follows the module's mode like ``nn.BatchNorm2d``: ``.eval()`` = running statistics folded into the
+convolutions — the canonical, fast, frame-independent mode of SURVEY.md F2.  The reference's callers never call
+``.eval()``, so there BN uses batch statistics (frames of a batch influence each other); a model left in training
+mode runs exactly that on the exact-fp32 kernels (a slow parity path, with a one-time warning) unless
+``bn_running_stats_in_train`` asks for eval semantics regardless of the mode.
 """
 import ctypes as C
 import json
@@ -95,6 +95,8 @@ class Darknet(nn.Module):
         self.CUDA = CUDA
         self.TRAIN = False
         self.bn_running_stats_in_train = False
+        self._warned_batch_bn = False
+        self.update_running_stats = True   # training-mode forward updates running_mean / running_var / num_batches_tracked like torch does
         self.precision = os.environ.get("RTOD_PRECISION", "auto")   # "fp32" (exact MFMA) | "f16s3" (split f16, 3 products) | "auto"
         self.keep_all_layers = False      # debug: no activation-arena reuse (read_layer after forward)
         self.autotune = True              # split-f16 plans: measure the tile variants once per batch size (rtod_plan_autotune)
@@ -109,6 +111,7 @@ class Darknet(nn.Module):
         self._plan = None
         self._plan_key = None
         self._weights_version = 0
+        self._stats_version = 0             # running_mean / running_var updates of training-mode forwards (eval plans fold them)
         self._plan_weights_version = -1
         self._info = None
 
@@ -250,7 +253,23 @@ class Darknet(nn.Module):
         inp_dim = int(self.net_info["height"])
         if self.precision not in ("fp32", "f16s3", "auto"):
             raise ValueError("Darknet.precision must be 'fp32', 'f16s3' or 'auto'")
-        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers), self.precision, tuple(sorted(self.options.items())))
+        # BatchNorm semantics follow the module's mode like nn.BatchNorm2d: eval() = running statistics, folded into the convs
+        # (the fast path, frame-independent); training mode = the statistics of the batch — what the reference's callers
+        # actually run, since they never call .eval() (detect.py:185-194).  That mode is a parity path on the
+        # exact-fp32 kernels (conv -> per-channel statistics -> normalise), several times slower and batch-dependent.
+        batch_bn = bool(self.training and not self.bn_running_stats_in_train)
+        if batch_bn and self.precision == "f16s3":
+            raise RuntimeError("Darknet is in training mode (batch-statistics BatchNorm, like the reference without .eval()): that "
+                               "path runs on the exact-fp32 kernels only; call .eval() for the split-f16 kernels or set precision='auto'")
+        if batch_bn and not self._warned_batch_bn:
+            warnings.warn("Darknet is in training mode: BatchNorm uses the statistics of the batch, as the reference does when its "
+                          "callers skip .eval() (slow parity path, results depend on the batch); call .eval() for the fast, "
+                          "frame-independent path", RuntimeWarning)
+            self._warned_batch_bn = True
+        opts = dict(self.options)
+        if batch_bn:
+            opts["bn_batch_stats"] = 1
+        key = (inp_dim, int(max_batch), device.index, bool(self.keep_all_layers), "fp32" if batch_bn else self.precision, tuple(sorted(opts.items())))
         if self._plan is None or self._plan_key != key:
             self._destroy_plan()
             h = C.c_void_p()
@@ -260,14 +279,14 @@ class Darknet(nn.Module):
             self._tuned = set()
             if self.keep_all_layers:
                 _ffi.check(lib.rtod_plan_set_keep_all_layers(self._plan, 1))
-            for name, value in sorted(self.options.items()):
+            for name, value in sorted(opts.items()):
                 _ffi.check(lib.rtod_plan_set_option(self._plan, name.encode(), int(value)))
             if self._ovf is None or self._ovf.device != device:
                 self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
             _ffi.check(lib.rtod_plan_set_overflow_flag(self._plan, C.c_void_p(self._ovf.data_ptr())))
             # "auto": the split-f16 kernels when the cfg supports them (yolov3 does; cfgs with maxpool or
             # Cin % 32 != 0 such as yolov3-tiny do not), else the exact-fp32 MFMA kernels.  Both are HIP paths.
-            if self.precision == "fp32":
+            if self.precision == "fp32" or batch_bn:
                 self.active_precision = "fp32"
             else:
                 rc = lib.rtod_plan_set_precision(self._plan, 1)
@@ -283,11 +302,12 @@ class Darknet(nn.Module):
             info = _ffi.PlanInfo()
             _ffi.check(lib.rtod_plan_get_info(self._plan, C.byref(info)))
             self._info = info
-        if self._plan_weights_version != self._weights_version:
+        version = (self._weights_version, 0 if batch_bn else self._stats_version)
+        if self._plan_weights_version != version:
             w = np.ascontiguousarray(self.weight_stream())
             with torch.cuda.device(device):
                 _ffi.check(lib.rtod_plan_load_weights(self._plan, w.ctypes.data_as(C.c_void_p), w.size))
-            self._plan_weights_version = self._weights_version
+            self._plan_weights_version = version
         return self._info
 
     def plan_description(self) -> dict:
@@ -317,11 +337,6 @@ class Darknet(nn.Module):
         if x.size(2) != inp_dim or x.size(3) != inp_dim:
             raise ValueError("Darknet.forward: input is %dx%d but net_info['height'] = %d (set it like detect.py:47 does)"
                              % (x.size(2), x.size(3), inp_dim))
-        if self.training and not self.bn_running_stats_in_train:
-            raise NotImplementedError(
-                "Darknet is in training mode: the reference would run BatchNorm on batch statistics (its callers "
-                "never call .eval(), SURVEY.md F2). This path implements running-statistics BN only: call "
-                ".eval() (or set bn_running_stats_in_train=True to accept eval semantics).")
         return inp_dim
 
     def forward(self, x, _launch_ms=None):
@@ -344,6 +359,8 @@ class Darknet(nn.Module):
                     _ffi.check(lib.rtod_forward(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream))
             else:
                 _ffi.check(lib.rtod_forward_timed(self._plan, C.c_void_p(x.data_ptr()), B, C.c_void_p(out.data_ptr()), stream, _launch_ms))
+        if self.training and not self.bn_running_stats_in_train and self.update_running_stats and _launch_ms is None:
+            self._update_running_stats(B, stream)
         # attributes the reference sets as a side effect of forward (src/darknet.py:239-243, 260)
         anchors = []
         for m, blk in zip(self.module_list, self.blocks[1:]):
@@ -365,6 +382,37 @@ class Darknet(nn.Module):
                 if len(_pending_overflow) > 64:
                     _pending_overflow.pop(next(iter(_pending_overflow)))
         return out
+
+    def _update_running_stats(self, batch, stream):
+        """Training-mode side effect of nn.BatchNorm2d (momentum 0.1): running_mean / running_var move towards the batch's mean
+        and UNBIASED variance, num_batches_tracked counts up — the reference mutates them on every forward."""
+        lib = _ffi.lib()
+        changed = False
+        ir = build_ir(self.blocks, int(self.net_info["height"]))
+        for i, (m, blk) in enumerate(zip(self.module_list, self.blocks[1:])):
+            if blk["type"] != "convolutional":
+                continue
+            bn = None
+            for sub in m.children():
+                if isinstance(sub, nn.BatchNorm2d):
+                    bn = sub
+            if bn is None:
+                continue
+            c = bn.num_features
+            mean = np.empty(c, dtype=np.float64)
+            var = np.empty(c, dtype=np.float64)
+            _ffi.check(lib.rtod_plan_bn_batch_stats(self._plan, i, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), c, stream))
+            L = ir.layers[i]
+            n = batch * L.hout * L.wout
+            unbiased = var * (n / max(1, n - 1))
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            with torch.no_grad():
+                bn.running_mean.mul_(1 - mom).add_(torch.from_numpy((mom * mean).astype(np.float32)).to(bn.running_mean.device))
+                bn.running_var.mul_(1 - mom).add_(torch.from_numpy((mom * unbiased).astype(np.float32)).to(bn.running_var.device))
+                bn.num_batches_tracked += 1
+            changed = True
+        if changed:
+            self._stats_version += 1            # an eval-mode plan built later folds the updated statistics
 
     def overflowed(self) -> bool:
         """True when a split-f16 producer saturated since the last call (one small host sync); clears the flag."""

@@ -102,6 +102,23 @@ def test_cfg_extensions_parse_identically_on_both_sides():
         _ffi.lib().rtod_plan_destroy(h)
 
 
+def test_batch_statistics_bn_is_an_fp32_plan_option():
+    """Option bn_batch_stats (the reference's as-run BatchNorm): exact-fp32 plans only, same launch list
+    (the statistics / normalisation kernels ride the conv launches), no dedicated stem kernel (layer 0 has BatchNorm)."""
+    rc, h = _plan(cfgs.yolov3_cfg(), 416)
+    assert rc == 0
+    lib = _ffi.lib()
+    info0 = _ffi.PlanInfo(); assert lib.rtod_plan_get_info(h, C.byref(info0)) == 0
+    assert lib.rtod_plan_set_option(h, b"bn_batch_stats", 1) == 0, _ffi.last_error()
+    info1 = _ffi.PlanInfo(); assert lib.rtod_plan_get_info(h, C.byref(info1)) == 0
+    assert info1.n_launches == info0.n_launches + 1                      # input pack + generic conv instead of the stem kernel
+    assert lib.rtod_plan_set_precision(h, 1) != 0 and "bn_batch_stats" in _ffi.last_error()
+    assert lib.rtod_plan_set_precision(h, 0) == 0
+    mean = (C.c_double * 32)(); var = (C.c_double * 32)()
+    assert lib.rtod_plan_bn_batch_stats(h, 0, mean, var, 32, None) != 0    # no weights loaded / nothing run yet: refused, not a crash
+    lib.rtod_plan_destroy(h)
+
+
 def test_buffer_plan_has_no_live_overlap():
     rc, h = _plan(cfgs.yolov3_cfg(), 608)
     assert rc == 0

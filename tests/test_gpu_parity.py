@@ -362,8 +362,61 @@ def test_v5_style_blocks_vs_torch_ops(tmp_path_factory, precision, res, B):
         assert ms.active_precision == "fp32"
 
 
+# ------------------------------------------------------------------------------- as-run BatchNorm (training mode)
+@pytest.mark.parametrize("net,res,B", [("yolov3-tiny", 416, 2), ("yolov3", 416, 2), ("yolov3", 320, 3)])
+def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path_factory, net, res, B):
+    """The reference's callers never call .eval() (detect.py:185-194): nn.BatchNorm2d then normalises with
+    the statistics of the batch.  A Darknet left in training mode runs exactly that (exact-fp32 kernels: raw conv ->
+    per-channel mean / biased variance in double -> normalise + leaky + shortcut): output against the REAL reference run
+    in training mode (tests/golden/make_golden_trainbn.py), running_mean / running_var updated like torch updates them,
+    and the result depends on the batch (which is why eval mode is the canonical, shardable path)."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    g = np.load(os.path.join(golden_dir, "trainbn.npz"))
+    tag = "%s_%d_b%d" % (net, res, B)
+    cfg_text = NETS[net]()
+    d = tmp_path_factory.mktemp("trainbn_" + tag)
+    m = Darknet(cfgs.write_cfg(str(d / (net + ".cfg")), cfg_text), True)          # no .eval(): as detect.py builds it
+    assert m.training
+    m.net_info["height"] = res
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    m.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=31))
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="training mode"):
+        y = m(x.cuda())
+    assert m.active_precision == "fp32"
+    stride = int(g["stride_" + tag])
+    got = y.cpu().numpy()[:, ::stride]
+    # Tolerance of THIS mode: normalising by the statistics of 300-340 samples per channel (13x13 / 10x10 grids, batch 2-3)
+    # amplifies the convolutions' rounding differences layer by layer (per-layer error reaches 3-5e-5 of absmax at layers
+    # 79-85 where eval mode stays below 2e-5; measured, tools/dbg_trainbn.py) — different BLAS back ends of the reference
+    # disagree at the same level.  99.9 % of the output within the path's 1e-4, the tail (w / h columns: exp) within 5e-4.
+    e = rel_err(got, g["rows_" + tag])
+    assert np.quantile(e, 0.999) <= TOL and e.max() <= 5e-4, (float(np.quantile(e, 0.999)), float(e.max()))
+    # side effect on the module buffers (momentum 0.1, unbiased variance), first and last BatchNorm layer
+    bns = [(i, mod) for i, seq in enumerate(m.module_list) for mod in seq.children() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for i, bn in (bns[0], bns[-1]):
+        assert np.allclose(bn.running_mean.cpu().numpy(), g["rmean_%s_L%d" % (tag, i)], rtol=1e-4, atol=1e-6)
+        assert np.allclose(bn.running_var.cpu().numpy(), g["rvar_%s_L%d" % (tag, i)], rtol=1e-4, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+    # batch-dependence: the same frame alone gives different rows (unlike eval mode, where they are bit-identical)
+    m.update_running_stats = False
+    with torch.no_grad():
+        y1 = m(x[:1].cuda())
+    assert not torch.equal(y1[0], y[0])
+    # ... and eval() afterwards is the folded fast path again, with the statistics the training-mode forward left behind
+    m.eval()
+    with torch.no_grad():
+        ye = m(x.cuda())
+    assert torch.isfinite(ye).all() and not torch.equal(ye, y)
+    m.precision = "f16s3"
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(x.cuda())
+
+
 # ------------------------------------------------------------------------------- error behaviour
-def test_fails_loudly_without_gpu_tensors_or_in_train_mode(tmp_path_factory):
+def test_fails_loudly_without_gpu_tensors(tmp_path_factory):
     from realtimeobjectdetection_amd.util import write_results, predict_transform
     m, _ = gpu_model("yolov3-tiny", 416, tmp_path_factory)
     x = torch.from_numpy(synth.synth_frames(1, 416))
@@ -371,10 +424,6 @@ def test_fails_loudly_without_gpu_tensors_or_in_train_mode(tmp_path_factory):
         m(x)                                                           # CPU tensor: no fallback
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 320, 320, device="cuda"))                  # net_info['height'] mismatch
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(x.cuda())
-    m.eval()
     with pytest.raises(RuntimeError):
         write_results(torch.zeros(1, 10, 85), 80)
     with pytest.raises(RuntimeError):

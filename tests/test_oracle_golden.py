@@ -240,3 +240,17 @@ def test_oracle_mini_networks_bit_identical_to_reference(golden_dir, tag, gen, r
         assert isinstance(det, int) and det == 0
     else:
         assert np.array_equal(canonical_ties(det.numpy()), canonical_ties(g[tag + "_det"]))
+
+
+@pytest.mark.parametrize("net,res,B", [("yolov3-tiny", 416, 2), ("yolov3", 416, 2), ("yolov3", 320, 3)])
+def test_oracle_batch_statistics_mode_bit_identical_to_reference(golden_dir, net, res, B):
+    """The oracle's batch-statistics BatchNorm (what the reference runs when its callers skip .eval())
+    against rows of the REAL reference left in training mode (tests/golden/make_golden_trainbn.py)."""
+    g = np.load(os.path.join(golden_dir, "trainbn.npz"))
+    tag = "%s_%d_b%d" % (net, res, B)
+    ref = O.RefDarknet(NETS[net](), res)
+    ref.load_weight_stream(synth.synth_weights(ref.ir))
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=31))
+    with torch.no_grad():
+        y = ref.forward(x, batch_stats=True).numpy()
+    assert np.array_equal(y[:, ::int(g["stride_" + tag])], g["rows_" + tag])
