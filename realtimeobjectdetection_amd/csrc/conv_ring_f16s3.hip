@@ -28,6 +28,10 @@
 // load and the epilogue switched off (RTOD_DIAG, tools/ablate_1x1.sh) these layers still take 14-18 of their 19-23 us: what a
 // step costs is issuing its LDS-DMA pieces (4-6 per wave and step at ~100-185 cycles each, MI355X_MICROARCH 'LDS-DMA piece issue
 // cost') against 288-384 cycles of MFMAs — tiles with more MFMA work per staged kilobyte are the lever, not the schedule.
+// In-workgroup split-K (two 8-wave groups on the even / odd chunks of a 64x128 tile, 184 workgroups at 19x19): correct
+// (1.5e-5 against the oracle) and exactly as fast as the autotuned tiles (19.9 vs 19.8-20.1 us) — halving the K loop does not
+// shorten these kernels: rocprofv3's per-dispatch trace shows ~4.5 us of every launch is dispatch + drain (a one-workgroup
+// kernel that writes 28 bytes takes 4.8 us there) and the weights of every layer arrive cold from HBM.
 #include "conv_f16s3_common.h"
 #include <atomic>
 #include <cstdio>
