@@ -189,6 +189,15 @@ int rtod_write_results(const float* pred_dev, int batch, int n, int num_class, f
                        float nms_conf, float* out_dev, int cap, int32_t* counts_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* (new; YOLOv5-style post-processing — the reference's YOLOv5 path is a torch.hub fetch, detect.py:255-285, so this follows the
+ * published class-offset batched NMS, parity unpinned)  pred_dev [batch,n,5+num_class] rows (cx,cy,w,h,obj,cls...): candidates
+ * obj > confidence and conf = obj * max class score > confidence; greedy NMS by descending conf on boxes shifted by
+ * class * max_wh, suppression at IoU > iou_thr (no +1); rows [img,x1,y1,x2,y2,conf,obj,cls] per image by descending conf, at
+ * most max_det per image; counts as rtod_write_results; same workspace size.  Enqueues only. */
+int rtod_nms_class_offset(const float* pred_dev, int batch, int n, int num_class, float confidence, float iou_thr, float max_wh,
+                          int max_det, float* out_dev, int cap, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

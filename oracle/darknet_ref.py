@@ -218,3 +218,47 @@ def write_results(prediction, num_class: int, confidence: float = 0.6, nms_conf:
     if not out:
         return torch.zeros((0, 8), dtype=torch.float32)
     return torch.from_numpy(np.asarray(out, dtype=np.float32))
+
+
+def nms_class_offset(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, max_wh=7680.0, max_det=300) -> np.ndarray:
+    """CPU restatement of the published YOLOv5 post-processing (class-offset batched NMS).  NOT reference source: the
+    reference obtains YOLOv5 through torch.hub (detect.py:255-285), nothing of it exists offline, and torchvision is not
+    installed — so this follows the documented algorithm step by step in float32 numpy (PARITY UNPINNED): obj > conf_thres;
+    cls *= obj; box = xywh -> xyxy; (conf, j) = max over classes; conf > conf_thres; sort by conf descending; boxes +
+    j * max_wh; greedy NMS with IoU = inter / (a1 + a2 - inter) (no +1), suppress at IoU > iou_thres; first max_det.
+    Returns rows [img, x1, y1, x2, y2, conf, obj, cls]."""
+    p = prediction.detach().cpu().numpy().astype(np.float32)
+    rows = []
+    for b in range(p.shape[0]):
+        x = p[b]
+        x = x[x[:, 4] > np.float32(conf_thres)]
+        if not len(x):
+            continue
+        obj = x[:, 4].copy()
+        cls = x[:, 5:] * x[:, 4:5]
+        half_w, half_h = x[:, 2] / np.float32(2), x[:, 3] / np.float32(2)
+        box = np.stack([x[:, 0] - half_w, x[:, 1] - half_h, x[:, 0] + half_w, x[:, 1] + half_h], 1).astype(np.float32)
+        j = cls.argmax(1)                                    # first maximal index
+        conf = cls[np.arange(len(cls)), j]
+        keep = conf > np.float32(conf_thres)
+        box, conf, j, obj = box[keep], conf[keep], j[keep], obj[keep]
+        order = np.argsort(-conf, kind="stable")             # ties: lower row first
+        box, conf, j, obj = box[order], conf[order], j[order], obj[order]
+        sb = box + (j.astype(np.float32) * np.float32(max_wh))[:, None]
+        area = (sb[:, 2] - sb[:, 0]) * (sb[:, 3] - sb[:, 1])
+        alive = np.ones(len(sb), bool)
+        kept = []
+        for i in range(len(sb)):
+            if not alive[i]:
+                continue
+            kept.append(i)
+            if len(kept) == max_det:
+                break
+            iw = np.maximum(np.minimum(sb[i, 2], sb[i + 1:, 2]) - np.maximum(sb[i, 0], sb[i + 1:, 0]), np.float32(0))
+            ih = np.maximum(np.minimum(sb[i, 3], sb[i + 1:, 3]) - np.maximum(sb[i, 1], sb[i + 1:, 1]), np.float32(0))
+            inter = iw * ih
+            iou = inter / ((area[i] + area[i + 1:]) - inter)
+            alive[i + 1:] &= ~(iou > np.float32(iou_thres))
+        for i in kept:
+            rows.append([b, box[i, 0], box[i, 1], box[i, 2], box[i, 3], conf[i], obj[i], j[i]])
+    return np.array(rows, dtype=np.float32).reshape(-1, 8)

@@ -282,4 +282,12 @@ int rtod_write_results(const float* pred_dev, int batch, int n, int num_class, f
     RTOD_GUARD_END
 }
 
+int rtod_nms_class_offset(const float* pred_dev, int batch, int n, int num_class, float confidence, float iou_thr, float max_wh, int max_det,
+                          float* out_dev, int cap, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    RTOD_GUARD_BEGIN
+    return launch_nms_class_offset(pred_dev, batch, n, num_class, confidence, iou_thr, max_wh, max_det, out_dev, cap, counts_dev,
+                                   workspace_dev, workspace_bytes, (hipStream_t)stream);
+    RTOD_GUARD_END
+}
+
 }  // extern "C"

@@ -76,6 +76,9 @@ __device__ __forceinline__ uint32_t float_desc_key(float v) {
 }
 
 // ------------------------------------------------------------------------------------------ K1
+// V5 = true: the YOLOv5-style variant (class-offset batched NMS; not reference behaviour, see launch_nms_class_offset):
+// candidates need obj > conf AND obj * best class score > conf, the sort key carries that product.
+template <bool V5>
 __global__ __launch_bounds__(256)
 void nms_filter_kernel(const float* __restrict__ pred, int B, int n, int num_class, float conf, NmsWs w) {
     const int attrs = 5 + num_class;
@@ -118,13 +121,14 @@ void nms_filter_kernel(const float* __restrict__ pred, int B, int n, int num_cla
             const float hw = bw / 2.0f, hh = bh / 2.0f;
             float* rec = w.rec + ((int64_t)b * n + r) * 8;
             f32x4 lo = {cx - hw, cy - hh, cx + hw, cy + hh};
-            f32x4 hi = {obj, best, (float)bi, 0.f};
+            const float score = V5 ? obj * best : obj;             // V5: conf = obj * cls (one rounding, as x[:, 5:] *= x[:, 4:5])
+            f32x4 hi = V5 ? f32x4{score, obj, (float)bi, 0.f} : f32x4{obj, best, (float)bi, 0.f};
             *reinterpret_cast<f32x4*>(rec) = lo;
             *reinterpret_cast<f32x4*>(rec + 4) = hi;
-            if (best != 0.0f) {                    // class rows with score == 0 are dropped  util.py:305
+            if (V5 ? (score > conf) : (best != 0.0f)) {    // reference: class rows with score == 0 are dropped  util.py:305
                 const int slot = atomicAdd(&w.cand[b], 1);
                 const uint64_t key = ((uint64_t)bi << (32 + NMS_ROW_BITS)) |
-                                     ((uint64_t)float_desc_key(obj) << NMS_ROW_BITS) | (uint64_t)r;
+                                     ((uint64_t)float_desc_key(score) << NMS_ROW_BITS) | (uint64_t)r;
                 if (slot < w.P) w.keys[(int64_t)b * w.P + slot] = key;   // (always true with zeroed counters; never write past the image's slots)
             }
         }
@@ -144,8 +148,21 @@ __device__ __forceinline__ float iou_ref(const f32x4 a, const f32x4 b) {
     return inter / ((a1 + a2) - inter);
 }
 
+// IoU of the class-offset batched NMS: boxes shifted by class * max_wh before the test (so that one NMS pass serves all
+// classes; the shift costs coordinate bits in fp32 and is therefore restated, not optimised away), no +1, no contraction.
+__device__ __forceinline__ float iou_offset(const f32x4 a, const f32x4 b, float shift) {
+    const float ax1 = a[0] + shift, ay1 = a[1] + shift, ax2 = a[2] + shift, ay2 = a[3] + shift;
+    const float bx1 = b[0] + shift, by1 = b[1] + shift, bx2 = b[2] + shift, by2 = b[3] + shift;
+    const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.0f);
+    const float ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.0f);
+    const float inter = iw * ih;
+    const float a1 = (ax2 - ax1) * (ay2 - ay1), a2 = (bx2 - bx1) * (by2 - by1);
+    return inter / ((a1 + a2) - inter);
+}
+
+template <bool V5>
 __global__ __launch_bounds__(NMS_BLOCK)
-void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w) {
+void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w, float max_wh, int max_det) {
     __shared__ uint64_t s_keys[NMS_LDS_CAP];
     __shared__ uint8_t s_alive[NMS_LDS_CAP];
     __shared__ int s_scan[NMS_BLOCK / 64 + 1];
@@ -211,8 +228,12 @@ void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w) {
             for (int j = i + 1 + lane; j < s1; j += 64) {
                 if (!alive[j]) continue;
                 const f32x4 bj = *reinterpret_cast<const f32x4*>(rec + (keys[j] & rowmask) * 8);
-                const float iou = iou_ref(bi, bj);
-                if (!(iou < nms_thr)) alive[j] = 0;                // keep iff iou < thr (strict)
+                if constexpr (V5) {
+                    if (iou_offset(bi, bj, (float)cls * max_wh) > nms_thr) alive[j] = 0;   // suppressed iff iou > thr
+                } else {
+                    const float iou = iou_ref(bi, bj);
+                    if (!(iou < nms_thr)) alive[j] = 0;            // keep iff iou < thr (strict)
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -236,7 +257,38 @@ void nms_sort_suppress_kernel(int n, float nms_thr, NmsWs w) {
         base += tot;                           //   or, on the global path, positions < i were already read)
         __syncthreads();
     }
-    if (tid == 0) w.ndet[b] = base;
+    if constexpr (V5) {
+        // survivors are in (class, score) order; the batched NMS returns them by descending score over all classes, capped
+        // at max_det: re-key by (score desc, row asc) and sort once more
+        __syncthreads();
+        int Q = 1; while (Q < base) Q <<= 1;
+        uint64_t* k2 = (Q <= NMS_LDS_CAP) ? s_keys : gk;
+        for (int i = tid; i < Q; i += NMS_BLOCK) {                // (global path: in place — a thread rewrites only the slot it read)
+            uint64_t k = ~0ull;
+            if (i < base) {
+                const uint64_t row = gk[i] & rowmask;
+                k = ((uint64_t)float_desc_key(rec[row * 8 + 4]) << NMS_ROW_BITS) | row;
+            }
+            k2[i] = k;
+        }
+        __syncthreads();
+        for (int k = 2; k <= Q; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (Q >> 1); t += NMS_BLOCK) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const uint64_t a = k2[i], c = k2[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { k2[i] = c; k2[l] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        if (k2 != gk) for (int i = tid; i < base; i += NMS_BLOCK) gk[i] = k2[i];
+        if (tid == 0) w.ndet[b] = base < max_det ? base : max_det;
+    } else {
+        if (tid == 0) w.ndet[b] = base;
+    }
 }
 
 __global__ void nms_zero_kernel(int32_t* __restrict__ p, int n) {
@@ -283,10 +335,31 @@ int launch_write_results(const float* pred, int batch, int n, int num_class, flo
     // of the previous replay in place on ROCm 7.2 (second replay: candidates appended past the buffers, GPU fault)
     hipLaunchKernelGGL(nms_zero_kernel, dim3(1), dim3(64), 0, s, w.cand, 3 * batch + 4);
     const int waves = batch * ((n + 63) / 64);
-    hipLaunchKernelGGL(nms_filter_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, pred, batch, n, num_class, conf, w);
-    hipLaunchKernelGGL(nms_sort_suppress_kernel, dim3(batch), dim3(NMS_BLOCK), 0, s, n, nms, w);
+    hipLaunchKernelGGL(nms_filter_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, s, pred, batch, n, num_class, conf, w);
+    hipLaunchKernelGGL(nms_sort_suppress_kernel<false>, dim3(batch), dim3(NMS_BLOCK), 0, s, n, nms, w, 0.f, 0);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(batch), dim3(256), 0, s, batch, n, w, out, cap, counts);
     return hip_fail(hipGetLastError(), "write_results launch");
+}
+
+// Class-offset batched NMS (YOLOv5-style post-processing; cfg-extension companion, NOT reference behaviour: the reference's
+// YOLOv5 path is a torch.hub fetch, detect.py:255-285).  pred [batch,n,5+C] rows (cx,cy,w,h,obj,cls...): keep obj > conf, conf =
+// obj * max class score > conf; greedy NMS by descending conf on boxes shifted by class * max_wh, suppression at IoU > thr
+// (no +1); rows out [img,x1,y1,x2,y2,conf,obj,cls], per image by descending conf (ties: lower row first), at most max_det.
+int launch_nms_class_offset(const float* pred, int batch, int n, int num_class, float conf, float iou_thr, float max_wh, int max_det,
+                            float* out, int cap, int32_t* counts, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!pred || !out || !counts || !ws) { set_error("nms_class_offset: null pointer"); return RTOD_E_ARG; }
+    if (batch < 1 || n < 1 || num_class < 1 || num_class > NMS_MAX_CLASSES || n >= (1 << NMS_ROW_BITS) || cap < 0 || max_det < 1 || !(max_wh >= 0.f)) {
+        set_error("nms_class_offset: unsupported shape (batch=%d n=%d classes=%d)", batch, n, num_class); return RTOD_E_ARG;
+    }
+    if (ws_bytes < nms_workspace_bytes(batch, n)) { set_error("nms_class_offset: workspace too small"); return RTOD_E_ARG; }
+    if (((uintptr_t)ws & 15) || ((uintptr_t)out & 15)) { set_error("nms_class_offset: workspace/out must be 16-byte aligned"); return RTOD_E_ARG; }
+    NmsWs w = carve(ws, batch, n);
+    hipLaunchKernelGGL(nms_zero_kernel, dim3(1), dim3(64), 0, s, w.cand, 3 * batch + 4);
+    const int waves = batch * ((n + 63) / 64);
+    hipLaunchKernelGGL(nms_filter_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, pred, batch, n, num_class, conf, w);
+    hipLaunchKernelGGL(nms_sort_suppress_kernel<true>, dim3(batch), dim3(NMS_BLOCK), 0, s, n, iou_thr, w, max_wh, max_det);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(batch), dim3(256), 0, s, batch, n, w, out, cap, counts);
+    return hip_fail(hipGetLastError(), "nms_class_offset launch");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -201,5 +201,7 @@ int launch_bbox_iou(const float* box1, const float* boxes, int k, int row_stride
 size_t nms_workspace_bytes(int batch, int n);
 int launch_write_results(const float* pred, int batch, int n, int num_class, float conf, float nms,
                          float* out, int cap, int32_t* counts, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_nms_class_offset(const float* pred, int batch, int n, int num_class, float conf, float iou_thr, float max_wh, int max_det,
+                            float* out, int cap, int32_t* counts, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace rtod

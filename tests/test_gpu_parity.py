@@ -415,6 +415,45 @@ def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path
         m(x.cuda())
 
 
+# ------------------------------------------------------------------------------- class-offset batched NMS (YOLOv5-style)
+def _v5_predictions(seed, B, n, C, clusters, spread, obj_lo=0.0):
+    """Boxes drawn around a few cluster centres (so that suppression really happens), independent objectness / class scores."""
+    rng = np.random.default_rng(seed)
+    p = np.zeros((B, n, 5 + C), np.float32)
+    cen = rng.uniform(80, 560, (B, clusters, 2)).astype(np.float32)
+    which = rng.integers(0, clusters, (B, n))
+    p[..., 0:2] = np.take_along_axis(cen, which[..., None].repeat(2, -1), 1) + rng.normal(0, spread, (B, n, 2))
+    p[..., 2:4] = rng.uniform(30, 160, (B, n, 2))
+    p[..., 4] = rng.uniform(obj_lo, 1, (B, n))
+    p[..., 5:] = rng.uniform(0, 1, (B, n, C)) ** 6
+    hot = rng.integers(0, min(C, 6), (B, n))                          # a few popular classes: same-class overlaps
+    np.put_along_axis(p[..., 5:], hot[..., None], rng.uniform(0.5, 1, (B, n, 1)).astype(np.float32), -1)
+    return p
+
+
+@pytest.mark.parametrize("seed,B,n,C,clusters,spread,conf,iou,max_det", [
+    (1, 2, 1500, 80, 12, 25.0, 0.25, 0.45, 300),
+    (2, 3, 4000, 20, 5, 40.0, 0.30, 0.50, 300),
+    (3, 1, 900, 1, 3, 15.0, 0.10, 0.60, 50),                          # one class, tight cap
+    (4, 2, 12000, 80, 30, 30.0, 0.05, 0.45, 1000),                    # > 8192 candidates per image: the global-memory sort path
+    (5, 2, 300, 80, 4, 10.0, 0.95, 0.45, 300),                        # almost nothing passes; an image may have no detection
+])
+def test_class_offset_nms_vs_published_algorithm(seed, B, n, C, clusters, spread, conf, iou, max_det):
+    """SURVEY.md §8(f) row 4 prerequisite: YOLOv5-style post-processing.  PARITY UNPINNED (no YOLOv5 source offline, no
+    torchvision): the GPU kernels against a step-by-step float32 restatement of the published algorithm
+    (oracle.nms_class_offset) — selection, order and every value bit-exact on identical inputs."""
+    from realtimeobjectdetection_amd.util import nms_class_offset
+    p = _v5_predictions(seed, B, n, C, clusters, spread)
+    want = O.nms_class_offset(torch.from_numpy(p), conf, iou, 7680.0, max_det)
+    got = nms_class_offset(torch.from_numpy(p).cuda(), C, conf, iou, 7680.0, max_det).cpu().numpy()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want)
+    if len(want):
+        for b in range(B):                                                # per image: descending conf, at most max_det
+            c = want[want[:, 0] == b][:, 5]
+            assert len(c) <= max_det and np.all(c[:-1] >= c[1:])
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_fails_loudly_without_gpu_tensors(tmp_path_factory):
     from realtimeobjectdetection_amd.util import write_results, predict_transform
