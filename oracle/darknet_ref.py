@@ -103,7 +103,7 @@ class RefDarknet:
                 else:
                     x = torch.cat([outputs[s] for s in L.srcs], 1)
             elif L.type == "yolo":
-                x = predict_transform(x, self.height, L.anchors, L.classes)
+                x = (predict_transform_v5 if L.decode_v5 else predict_transform)(x, self.height, L.anchors, L.classes)
                 detections = x if detections is None else torch.cat((detections, x), 1)
                 outputs[i] = outputs[i - 1]
                 continue
@@ -113,6 +113,25 @@ class RefDarknet:
         return detections
 
     __call__ = forward
+
+
+def predict_transform_v5(prediction: torch.Tensor, inp_dim: int, anchors, num_class: int) -> torch.Tensor:
+    """YOLOv5-style head arithmetic (cfg extension ``decode=v5``; NOT reference source — the published Detect layer restated:
+    y = sigmoid(x); xy = (y * 2 - 0.5 + grid) * stride; wh = (y * 2) ** 2 * anchor (pixels); PARITY UNPINNED).  Rows are kept
+    in this path's order (cell-major, anchor inner), like predict_transform's."""
+    B, G = prediction.size(0), prediction.size(2)
+    stride = inp_dim // G
+    attrs, A = 5 + num_class, len(anchors)
+    p = prediction.reshape(B, attrs * A, G * G).transpose(1, 2).contiguous().view(B, G * G * A, attrs)
+    y = torch.sigmoid(p)
+    g = torch.arange(G)
+    gy, gx = torch.meshgrid(g, g, indexing="ij")
+    off = torch.stack((gx.reshape(-1), gy.reshape(-1)), 1).repeat(1, A).view(-1, 2).unsqueeze(0).float()
+    anc = torch.FloatTensor([(float(a[0]), float(a[1])) for a in anchors]).repeat(G * G, 1).unsqueeze(0)
+    out = y.clone()
+    out[:, :, 0:2] = (y[:, :, 0:2] * 2.0 - 0.5 + off) * stride
+    out[:, :, 2:4] = (y[:, :, 2:4] * 2) ** 2 * anc
+    return out
 
 
 def predict_transform(prediction: torch.Tensor, inp_dim: int, anchors, num_class: int,

@@ -62,6 +62,7 @@ class Layer:
     leaky: bool = False
     silu: bool = False             # extension (not in the reference grammar): activation=silu, x * sigmoid(x)
     nearest: bool = False          # extension: [upsample] mode=nearest (the reference always builds bilinear, darknet.py:589)
+    decode_v5: bool = False        # extension: [yolo] decode=v5 (YOLOv5-style head arithmetic)
     pool_pad: int = 0              # extension: [maxpool] symmetric=1 -> (size-1)//2 of -inf padding on every side (SPPF pools)
     srcs: Tuple[int, ...] = ()     # absolute source layer indices (route / shortcut)
     anchors: Tuple[Tuple[int, int], ...] = ()
@@ -160,6 +161,7 @@ def build_ir(blocks: List[dict], height: int, width: int = None) -> NetIR:
             pairs = [(a[j], a[j + 1]) for j in range(0, len(a), 2)]
             L.anchors = tuple(pairs[m] for m in mask)
             L.classes = int(b["classes"])
+            L.decode_v5 = b.get("decode", "") == "v5"
             L.cout, L.hout, L.wout = prev_c, prev_h, prev_w
             L.row_offset = row_off
             L.rows = prev_h * prev_w * len(L.anchors)

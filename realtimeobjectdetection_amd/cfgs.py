@@ -161,6 +161,83 @@ def v5_style_mini_cfg(height=128, width=128, classes=80, act="silu") -> str:
     return "\n".join(L) + "\n"
 
 
+def yolov5s_style_cfg(height=640, width=640, classes=80) -> str:
+    """A YOLOv5s-SHAPED graph in the extended cfg grammar, written from the PUBLISHED architecture description of YOLOv5 v6.0
+    (yolov5s: width 0.50, depth 0.33 — CSP backbone of C3 blocks, SPPF, PANet neck, three Detect heads) — NOT from its source,
+    which the reference only reaches through torch.hub (detect.py:255-285) and which does not exist offline.  It is a workload of
+    BASELINE config (5)'s shape for the kernels (synthetic weights, parity unpinned), nothing more.
+        Conv        = [convolutional] batch_normalize=1, activation=silu
+        C3(c, n, s) = cv1 1x1 c/2 -> n x (1x1, 3x3 [, + shortcut]); cv2 1x1 c/2 on the block input; concat; cv3 1x1 c
+        SPPF        = 1x1 c/2; three chained 5x5 stride-1 symmetric max-pools; concat of all four; 1x1 c
+        Detect      = 1x1 linear conv to 3 * (5 + classes) per scale, [yolo] decode=v5
+    Extension keys used: activation=silu, [maxpool] symmetric=1, [upsample] mode=nearest, [yolo] decode=v5, 4-source [route]."""
+    nout = 3 * (5 + classes)
+    L = _net(height, width)
+    n = [0]                                            # running layer index
+
+    def emit(lines):
+        L.extend(lines)
+        n[0] += 1
+        return n[0] - 1
+
+    def conv(c, k, s):
+        return emit(_conv(c, k, s, act="silu"))
+
+    def route(*idx):
+        return emit(_route(*idx))
+
+    def c3(x, c, reps, shortcut):
+        h = c // 2
+        if x != n[0] - 1:
+            route(x)
+        m = conv(h, 1, 1)                              # cv1
+        for _ in range(reps):
+            conv(h, 1, 1)
+            m2 = conv(h, 3, 1)
+            m = emit(_shortcut(-3)) if shortcut else m2
+        route(x)
+        b = conv(h, 1, 1)                              # cv2 on the block input
+        route(m, b)
+        return conv(c, 1, 1)                           # cv3
+
+    conv(32, 6, 2)                                     # 0  P1/2
+    x = conv(64, 3, 2)                                 #    P2/4
+    x = c3(x, 64, 1, True)
+    x = conv(128, 3, 2)                                #    P3/8
+    p3 = c3(x, 128, 2, True)
+    x = conv(256, 3, 2)                                #    P4/16
+    p4 = c3(x, 256, 3, True)
+    x = conv(512, 3, 2)                                #    P5/32
+    x = c3(x, 512, 1, True)
+    s0 = conv(256, 1, 1)                               # SPPF
+    s1 = emit(["[maxpool]", "size=5", "stride=1", "symmetric=1", ""])
+    s2 = emit(["[maxpool]", "size=5", "stride=1", "symmetric=1", ""])
+    s3 = emit(["[maxpool]", "size=5", "stride=1", "symmetric=1", ""])
+    route(s0, s1, s2, s3)
+    x = conv(512, 1, 1)
+    h10 = conv(256, 1, 1)                              # neck, top-down
+    emit(["[upsample]", "stride=2", "mode=nearest", ""])
+    route(n[0] - 1, p4)
+    x = c3(n[0] - 1, 256, 1, False)
+    h14 = conv(128, 1, 1)
+    emit(["[upsample]", "stride=2", "mode=nearest", ""])
+    route(n[0] - 1, p3)
+    o3 = c3(n[0] - 1, 128, 1, False)                   # P3/8 output
+    conv(128, 3, 2)                                    # bottom-up
+    route(n[0] - 1, h14)
+    o4 = c3(n[0] - 1, 256, 1, False)                   # P4/16 output
+    conv(256, 3, 2)
+    route(n[0] - 1, h10)
+    o5 = c3(n[0] - 1, 512, 1, False)                   # P5/32 output
+    for src, mask in ((o3, (0, 1, 2)), (o4, (3, 4, 5)), (o5, (6, 7, 8))):
+        if src != n[0] - 1:
+            route(src)
+        emit(_conv(nout, 1, 1, bn=False, act="linear"))
+        y = _yolo(mask, _ANCHORS_V3, 9, classes)
+        emit(y[:-1] + ["decode=v5", ""])
+    return "\n".join(L) + "\n"
+
+
 def write_cfg(path, text):
     with open(path, "w") as f:
         f.write(text)

@@ -433,6 +433,11 @@ __global__ void decode_kernel(const float* __restrict__ raw, int64_t sb, int64_t
         const int a = n / d.attrs, c = n - a * d.attrs;
         float v = raw[b * sb + (int64_t)n * sc + (int64_t)gy * sy + (int64_t)gx * sx];
         if (c >= 4) v = sigm(v);
+        else if (d.v5) {                                 // YOLOv5-style head (cfg extension)
+            const float sg = sigm(v);
+            if (c < 2) v = ((sg * 2.0f - 0.5f) + (float)(c == 0 ? gx : gy)) * d.stride;
+            else { const float t2 = sg * 2.0f; v = (t2 * t2) * (c == 2 ? d.aw[a] : d.ah[a]); }
+        }
         else if (c < 2) { v = sigm(v); if (!d.train) v = (v + (float)(c == 0 ? gx : gy)) * d.stride; }
         else if (!d.train) v = (expf(v) * (c == 2 ? d.aw[a] : d.ah[a])) * d.stride;
         out[b * d.img_stride + d.head_off + r] = v;

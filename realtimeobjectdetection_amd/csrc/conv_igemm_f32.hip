@@ -41,6 +41,12 @@ __device__ __forceinline__ float decode_value(const DecodeArgs& d, float v, int 
     const int a = n / d.attrs;
     const int c = n - a * d.attrs;
     if (c >= 4) return sigmoidf_(v);
+    if (d.v5) {                                     // YOLOv5-style head (cfg extension): operation order of the published Detect layer
+        const float s = sigmoidf_(v);
+        if (c < 2) return ((s * 2.0f - 0.5f) + (float)(c == 0 ? gx : gy)) * d.stride;
+        const float t = s * 2.0f;
+        return (t * t) * (c == 2 ? d.aw[a] : d.ah[a]);
+    }
     if (c < 2) {
         float s = sigmoidf_(v);
         if (d.train) return s;

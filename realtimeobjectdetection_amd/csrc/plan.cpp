@@ -170,7 +170,7 @@ int Plan::parse(const std::string& text) {
                 if (!to_int(tok, v)) { set_error("cfg: layer %d: bad route entry '%s'", i, tok.c_str()); return RTOD_E_CFG; }
                 L.srcs.push_back(v > 0 ? v : i + v);           // positive = absolute (darknet.py:274-275)
             }
-            if (L.srcs.empty() || L.srcs.size() > 2) {         // the reference handles one or two sources only
+            if (L.srcs.empty() || L.srcs.size() > 4) {         // the reference handles one or two sources; up to four here (SPPF-style concats: cfg extension)
                 set_error("cfg: layer %d: route with %zu sources unsupported", i, L.srcs.size()); return RTOD_E_CFG;
             }
         } else if (b.type == "yolo") {
@@ -185,6 +185,8 @@ int Plan::parse(const std::string& text) {
                 L.anchors.push_back({av[2 * v], av[2 * v + 1]});
             }
             CFG_INT(b, "classes", L.classes);
+            auto dv = b.kv.find("decode");                // cfg extension: decode=v5
+            L.decode_v5 = dv != b.kv.end() && dv->second == "v5";
             if (L.anchors.empty() || L.anchors.size() > 4) { set_error("cfg: layer %d: 1..4 anchors per head supported", i); return RTOD_E_CFG; }
         } else {
             set_error("Unknown block error: A unknown block is provided: [%s]", b.type.c_str());   // darknet.py:524-526
@@ -417,7 +419,9 @@ int Plan::plan_buffers() {
                         for (size_t a = 0; a < F.anchors.size(); ++a) {
                             d.aw[a] = (float)((double)F.anchors[a].first / (double)stride);     // Python float divide -> FloatTensor (util.py:213-216)
                             d.ah[a] = (float)((double)F.anchors[a].second / (double)stride);
+                            if (F.decode_v5) { d.aw[a] = (float)F.anchors[a].first; d.ah[a] = (float)F.anchors[a].second; }   // pixels
                         }
+                        d.v5 = F.decode_v5 ? 1 : 0;
                         d.img_stride = (int64_t)total_rows * attrs; d.head_off = (int64_t)F.row_offset * attrs;
                         l.dec = d;
                     }
@@ -448,7 +452,9 @@ int Plan::plan_buffers() {
                     for (size_t a = 0; a < L.anchors.size(); ++a) {
                         d.aw[a] = (float)((double)L.anchors[a].first / (double)stride);
                         d.ah[a] = (float)((double)L.anchors[a].second / (double)stride);
+                        if (L.decode_v5) { d.aw[a] = (float)L.anchors[a].first; d.ah[a] = (float)L.anchors[a].second; }
                     }
+                    d.v5 = L.decode_v5 ? 1 : 0;
                     d.img_stride = (int64_t)total_rows * attrs; d.head_off = (int64_t)L.row_offset * attrs;
                     l.dec = d;
                     launches.push_back(l);
@@ -507,6 +513,7 @@ bool Plan::uses_split(const Layer& L, int cin_p) const {
 }
 
 int Plan::check_split_supported() const {
+    for (const auto& L : layers) if (L.type == LT_YOLO && L.decode_v5) { set_error("precision f16s3 unsupported for this cfg (layer %d: decode=v5 heads run on the exact-fp32 kernels only); use fp32", L.index); return RTOD_E_CFG; }
     if (opt_bn_batch_stats) { set_error("precision f16s3 unsupported with bn_batch_stats (batch-statistics BatchNorm runs on the exact-fp32 kernels)"); return RTOD_E_CFG; }
     // precision 1 keeps every activation in the split f16 format: every conv but the stem must read
     // 32-channel K-chunks, every shortcut / head must ride a conv epilogue, concats must be zero-copy
@@ -1169,7 +1176,7 @@ std::string Plan::describe() const {
         if (i) os << ",";
         os << "{\"index\":" << L.index << ",\"type\":\"" << layer_type_name(L.type) << "\",\"cin\":" << L.cin << ",\"cout\":" << L.cout
            << ",\"hin\":" << L.hin << ",\"win\":" << L.win << ",\"hout\":" << L.hout << ",\"wout\":" << L.wout << ",\"size\":" << L.size
-           << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"bn\":" << (L.bn ? "true" : "false") << ",\"leaky\":" << (L.leaky ? "true" : "false") << ",\"act\":" << L.act << ",\"nearest\":" << (L.nearest ? "true" : "false") << ",\"pool_pad\":" << L.pool_pad
+           << ",\"stride\":" << L.stride << ",\"pad\":" << L.pad << ",\"bn\":" << (L.bn ? "true" : "false") << ",\"leaky\":" << (L.leaky ? "true" : "false") << ",\"act\":" << L.act << ",\"decode_v5\":" << (L.decode_v5 ? "true" : "false") << ",\"nearest\":" << (L.nearest ? "true" : "false") << ",\"pool_pad\":" << L.pool_pad
            << ",\"srcs\":[";
         for (size_t s = 0; s < L.srcs.size(); ++s) os << (s ? "," : "") << L.srcs[s];
         os << "],\"anchors\":[";

@@ -20,6 +20,7 @@ struct Layer {
     bool bn = false, leaky = false;
     int act = 0;                  // 0 linear, 1 leaky(0.1), 2 SiLU (cfg extension); leaky == (act == 1)
     bool nearest = false;         // upsample: mode=nearest (cfg extension; the reference builds bilinear)
+    bool decode_v5 = false;       // yolo: decode=v5 (cfg extension: YOLOv5-style head arithmetic)
     int pool_pad = 0;             // maxpool: symmetric=1 -> (size-1)/2 of -inf padding per side (cfg extension)
     std::vector<int> srcs;                       // absolute layer indices (route / shortcut)
     std::vector<std::pair<int, int>> anchors;    // yolo: masked (w,h) pairs

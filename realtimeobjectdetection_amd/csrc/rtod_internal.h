@@ -42,6 +42,8 @@ struct DecodeArgs {
     int attrs = 0;           // 5 + classes
     int n_anchors = 0;
     int train = 0;           // TRAIN=True: sigmoids only
+    int v5 = 0;              // cfg extension `[yolo] decode=v5` (YOLOv5-style heads): xy = (2 s - 0.5 + g) * stride, wh = (2 s)^2 * anchor
+                             // (aw / ah then hold the anchors in PIXELS), everything else sigmoid; not reference behaviour
     float stride = 0.f;      // inp_dim // G
     float aw[4] = {0, 0, 0, 0};   // fp32(anchor_w / stride)
     float ah[4] = {0, 0, 0, 0};

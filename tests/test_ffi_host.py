@@ -119,6 +119,31 @@ def test_batch_statistics_bn_is_an_fp32_plan_option():
     lib.rtod_plan_destroy(h)
 
 
+def test_yolov5s_style_graph_matches_published_counts_and_plans_without_fallback_kernels():
+    """cfgs.yolov5s_style_cfg restates the PUBLISHED YOLOv5s v6.0 architecture (no source offline): 16.4-16.5 GFLOPs at 640,
+    7.2 M parameters, 25 200 output rows — and the native planner agrees with the Python IR, fuses every shortcut / decode
+    and places every concat (incl. SPPF's four-way one) without copies."""
+    text = cfgs.yolov5s_style_cfg()
+    ir = build_ir(parse_cfg_text(text), 640)
+    assert ir.total_rows == 25200 and 7.2e6 < ir.n_weights < 7.3e6 and 16.4e9 < ir.conv_flops < 16.5e9
+    rc, h = _plan(text, 640)
+    assert rc == 0, _ffi.last_error()
+    d = _describe(h)
+    assert d["conv_flops"] == ir.conv_flops and d["n_weight_floats"] == ir.n_weights and d["total_rows"] == ir.total_rows
+    for L, D in zip(ir.layers, d["layers"]):
+        assert (L.type, L.cin, L.cout, L.hout, L.wout, L.size, L.stride, L.pad, list(L.srcs)) == (D["type"], D["cin"], D["cout"], D["hout"], D["wout"], D["size"], D["stride"], D["pad"], D["srcs"])
+        assert (L.decode_v5, L.nearest, L.pool_pad) == (D["decode_v5"], D["nearest"], D["pool_pad"])
+    info = _ffi.PlanInfo()
+    assert _ffi.lib().rtod_plan_get_info(h, C.byref(info)) == 0
+    kinds = []
+    for i in range(info.n_launches):
+        li = _ffi.LaunchInfo()
+        assert _ffi.lib().rtod_plan_get_launch(h, i, C.byref(li)) == 0
+        kinds.append(li.kind)
+    assert kinds.count(3) == kinds.count(5) == kinds.count(6) == 0 and kinds.count(0) == 60 and kinds.count(4) == 3 and kinds.count(2) == 2
+    _ffi.lib().rtod_plan_destroy(h)
+
+
 def test_buffer_plan_has_no_live_overlap():
     rc, h = _plan(cfgs.yolov3_cfg(), 608)
     assert rc == 0

@@ -415,6 +415,33 @@ def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path
         m(x.cuda())
 
 
+@pytest.mark.parametrize("res,B", [(320, 2), (640, 1)])
+def test_yolov5s_style_graph_vs_torch_ops(tmp_path_factory, res, B):
+    """BASELINE config (5)'s shape: a YOLOv5s-shaped graph (cfgs.yolov5s_style_cfg: the published architecture restated in the
+    extended cfg grammar, synthetic weights) through the exact-fp32 kernels — C3 / SPPF / PANet / decode=v5 heads — against the
+    oracle's PyTorch CPU ops, then class-offset batched NMS on both sides.  PARITY UNPINNED (no YOLOv5 source offline)."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd.util import nms_class_offset
+    cfg_text = cfgs.yolov5s_style_cfg()
+    d = tmp_path_factory.mktemp("v5s_%d" % res)
+    m = Darknet(cfgs.write_cfg(str(d / "v5s.cfg"), cfg_text), True).eval()
+    m.net_info["height"] = res
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    m.load_weight_stream(w)
+    ref.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=51))
+    with torch.no_grad():
+        want = ref.forward(x)
+        got = m(x.cuda())
+    assert m.active_precision == "fp32"                               # SiLU / decode=v5: exact-fp32 kernels ("auto" falls back)
+    assert got.shape == want.shape == (B, 3 * ((res // 8) ** 2 + (res // 16) ** 2 + (res // 32) ** 2), 85)
+    assert rel_err(got.cpu().numpy(), want.numpy()).max() <= TOL
+    dg = nms_class_offset(got, 80, 0.25, 0.45).cpu().numpy()
+    dw = O.nms_class_offset(got.cpu(), 0.25, 0.45)                    # identical input: bit-exact selection
+    assert np.array_equal(dg, dw)
+
+
 # ------------------------------------------------------------------------------- class-offset batched NMS (YOLOv5-style)
 def _v5_predictions(seed, B, n, C, clusters, spread, obj_lo=0.0):
     """Boxes drawn around a few cluster centres (so that suppression really happens), independent objectness / class scores."""
