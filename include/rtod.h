@@ -93,11 +93,11 @@ int rtod_plan_launch_kernel_name(const rtod_plan* plan, int index, char* buf, si
  *   1  split-precision f16 MFMA: a*w ~= ah*wh + ah*wl + al*wh with fp32 accumulation (22-bit
  *      operands, error ~2x fp32 per layer), 16x the MFMA rate per product.  Activations live in
  *      HBM as f16 hi/lo planes (x8 pre-scaled): needs |activation| < 8188, every conv after the
- *      stem with Cin % 32 == 0, no stand-alone shortcut / copy / decode launch, no activation=silu; otherwise RTOD_E_CFG.
+ *      stem with Cin % 32 == 0, no stand-alone shortcut / copy / decode launch; otherwise RTOD_E_CFG.
  * cfg grammar: the reference's (src/darknet.py:412-603) plus three extension keys for YOLOv5-style blocks (detect.py:255-285
  * fetches that model from the network; only its building blocks exist here): [convolutional] activation=silu,
  * [maxpool] symmetric=1 (-inf padding of (size-1)/2 per side), [upsample] mode=nearest, [yolo] decode=v5, [route] with up to
- * four sources.  SiLU and decode=v5 run on the exact-fp32 kernels only. */
+ * four sources. */
 int rtod_plan_set_precision(rtod_plan* plan, int mode);
 /* Plan options (call before rtod_plan_load_weights; re-plans buffers and launches).  All default to 1 / -1:
  *   "fuse_pointwise"    1x1 conv in the previous conv's epilogue where one workgroup holds all its input channels

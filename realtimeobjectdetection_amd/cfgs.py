@@ -138,8 +138,8 @@ def v5_style_mini_cfg(height=128, width=128, classes=80, act="silu") -> str:
     exercises the kernel-level pieces such a graph needs, each checked against PyTorch's own CPU op (parity unpinned):
     a 6x6 stride-2 pad-2 stem, SiLU activations (also on a residual block and on the hosted / fused epilogues), an SPPF-like
     run of 5x5 stride-1 pad-2 max-pools joined by routes, and nearest x2 upsampling.  Extension keys: activation=silu,
-    [maxpool] symmetric=1, [upsample] mode=nearest.  Every conv after the stem has Cin % 32 == 0; with ``act="leaky"`` the graph
-    is expressible in the split-f16 format (SiLU epilogues exist on the exact-fp32 kernels only)."""
+    [maxpool] symmetric=1, [upsample] mode=nearest.  Every conv after the stem has Cin % 32 == 0, so the graph is expressible in
+    the split-f16 format as well (SiLU there: the kernels with the LDS-transposed epilogue, i.e. generic and band tiles)."""
     nout = 3 * (5 + classes)
     L = _net(height, width)
     L += _conv(32, 6, 2, act=act)                                    # 0: 6x6 / 2 stem (pad = (6 - 1) // 2 = 2), 32 @ H/2

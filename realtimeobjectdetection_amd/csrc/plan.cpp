@@ -513,7 +513,7 @@ bool Plan::uses_split(const Layer& L, int cin_p) const {
 }
 
 int Plan::check_split_supported() const {
-    for (const auto& L : layers) if (L.type == LT_YOLO && L.decode_v5) { set_error("precision f16s3 unsupported for this cfg (layer %d: decode=v5 heads run on the exact-fp32 kernels only); use fp32", L.index); return RTOD_E_CFG; }
+
     if (opt_bn_batch_stats) { set_error("precision f16s3 unsupported with bn_batch_stats (batch-statistics BatchNorm runs on the exact-fp32 kernels)"); return RTOD_E_CFG; }
     // precision 1 keeps every activation in the split f16 format: every conv but the stem must read
     // 32-channel K-chunks, every shortcut / head must ride a conv epilogue, concats must be zero-copy
@@ -521,10 +521,6 @@ int Plan::check_split_supported() const {
         if (l.kind == LK_ADD || l.kind == LK_COPY || l.kind == LK_DECODE) {       // (max-pool and both upsamples have split-format kernels)
             set_error("precision f16s3 unsupported for this cfg (layer %d needs a stand-alone %s kernel); use fp32", l.layer,
                       l.kind == LK_ADD ? "add" : l.kind == LK_COPY ? "copy" : "decode");
-            return RTOD_E_CFG;
-        }
-        if ((l.kind == LK_CONV || l.kind == LK_STEM) && layers[l.layer].act == 2 && l.layer > 0) {
-            set_error("precision f16s3 unsupported for this cfg (layer %d: activation=silu runs on the exact-fp32 kernels only); use fp32", l.layer);
             return RTOD_E_CFG;
         }
         if (l.kind == LK_CONV && l.layer > 0) {
@@ -566,7 +562,7 @@ void Plan::layout_weights() {
             // stand-alone 1x1 conv (no shortcut / decode in its epilogue, not hosted by the previous conv): streaming kernel
             bool hosted = false;
             for (const auto& l : launches) if (l.kind == LK_CONV && l.layer == pc.layer && l.pw_host >= 0 && opt_fuse_pointwise) hosted = true;
-            pc.pw = opt_pw_kernel && !hosted && L.fused_into < 0 && conv_pw_supported(L.size, L.stride, L.pad, L.cin, L.cout);
+            pc.pw = opt_pw_kernel && !hosted && L.fused_into < 0 && L.act <= 1 && conv_pw_supported(L.size, L.stride, L.pad, L.cin, L.cout);
         } else {
             pc.w_off = packed_floats; packed_floats += panel;
             // deep small-grid layers (13x13 ... 52x52 stages, K >= 256): the K sum is formed in slices of 9 chunks (one 3x3 tap
@@ -910,13 +906,14 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
             if (pw && vi.bn < L.cout) continue;                                       // fused pointwise: one N tile
             cand.push_back(v);
         }
-        if (!pw && opt_patch_kernel && conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && L.hout == L.hin && l.out_layer != -2)
+        // (SiLU layers: only the kernels with the LDS-transposed epilogue carry that activation — generic and band tiles)
+        if (!pw && L.act <= 1 && opt_patch_kernel && conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && L.hout == L.hin && l.out_layer != -2)
             for (int m = 0; m < PATCH_MODES; ++m) {
                 if (conv_patch_mode_info(m).bn > L.cout && conv_patch_mode_info(m).bn > 64) continue;
                 if (!conv_patch_mode_valid(m, L.cin, L.cout)) continue;
                 cand.push_back(PATCH_VARIANT_BASE + m);
             }
-        if (!pw && opt_ring_kernel)
+        if (!pw && L.act <= 1 && opt_ring_kernel)
             for (int m = 0; m < RING_MODES; ++m) {
                 const ConvVariantInfo& vi = conv_ring_mode_info(m);
                 if (vi.bn > 2 * ((L.cout + 63) / 64 * 64) && vi.bn > 64) continue;
@@ -990,8 +987,8 @@ int Plan::variant_for(const Launch& l, int batch) const {
         const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
-        if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active())) return v;
-        if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 &&
+        if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active()) && FL.act <= 1) return v;
+        if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 && FL.act <= 1 &&
             conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, FL.cin, FL.cout)) return v;
         const int g = choose_variant_f16s3(layers[l.layer], batch);
         if (l.pw_guest >= 0 && pw_active() && conv_f16s3_variant_info(g).bn < layers[l.layer].cout) return HV_128x128_8W;

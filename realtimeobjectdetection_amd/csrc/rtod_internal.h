@@ -107,9 +107,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l, flo
     l = (_Float16)(vc - (float)h);
 }
 // Activation of a conv epilogue: 0 linear, 1 leaky(0.1) (src/darknet.py:497-501), 2 SiLU x * sigmoid(x) (cfg extension).
-// Exact-fp32 kernels and the stems only: the split-f16 epilogues know linear / leaky (a SiLU there measured 2.5 % on the
-// whole YOLOv3 forward — the compiler evaluates both arms per value — so split plans reject activation=silu and
-// precision="auto" runs such cfgs on the fp32 kernels).
+// Exact-fp32 kernels and the stems; the split-f16 epilogues have their own form (conv_f16s3_common.h: silu_scaled behind a
+// uniform branch around the loops of the LDS-transposed epilogue).
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return v > 0.f ? v : v * 0.1f;
     if (act == 2) return v / (1.0f + expf(-v));

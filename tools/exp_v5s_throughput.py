@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Datapoint for BASELINE config (5)'s SHAPE: the YOLOv5s-style graph (cfgs.yolov5s_style_cfg: published architecture restated,
-synthetic weights, parity unpinned) at 640x640 batch 8 on the exact-fp32 kernels (SiLU / decode=v5 have no split-f16 epilogue),
+synthetic weights, parity unpinned) at 640x640 batch 8 (--precision auto = split-f16 kernels, fp32 = exact-fp32 kernels),
 forward + class-offset batched NMS, HIP-event timed.   python tools/exp_v5s_throughput.py [--batch 8] [--res 640]"""
 import argparse, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,12 +11,13 @@ from realtimeobjectdetection_amd.darknet import Darknet
 from realtimeobjectdetection_amd.util import nms_class_offset
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--res", type=int, default=640)
-ap.add_argument("--iters", type=int, default=50); args = ap.parse_args()
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--precision", default="auto"); args = ap.parse_args()
 text = cfgs.yolov5s_style_cfg()
 ir = build_ir(parse_cfg_text(text), args.res)
 with tempfile.TemporaryDirectory() as d:
     m = Darknet(cfgs.write_cfg(os.path.join(d, "v5s.cfg"), text), True).eval()
     m.net_info["height"] = args.res
+    m.precision = args.precision
     m.load_weight_stream(synth.synth_weights(ir))
 x = torch.from_numpy(synth.synth_frames(args.batch, args.res)).cuda()
 with torch.no_grad():
