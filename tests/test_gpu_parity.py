@@ -220,6 +220,28 @@ def test_write_results_many_candidates_global_sort_path():
     assert np.array_equal(r.cpu().numpy(), want.numpy())
 
 
+@pytest.mark.parametrize("n,obj_mu,lo,hi,ncls", [(1000, -1.3, 60, 127, 80), (3000, -0.5, 300, 1000, 80), (3000, -0.5, 300, 1000, 3), (3000, -0.5, 300, 1000, 200),
+                                               (10647, -1.0, 1100, 2048, 80), (10647, -0.6, 2049, 4096, 80),
+                                               (10647, 0.3, 4097, 8192, 80), (22743, -1.5, 200, 2500, 80), (22743, -1.5, 200, 2500, 20)])
+def test_write_results_candidate_count_regimes(n, obj_mu, lo, hi, ncls):
+    """Up to 2048 candidates per image the keys are sorted by counting and suppression runs one thread per box, unless a class
+    holds more than 64 of them (3 classes: the per-segment loop; 200 classes: the filter's any-width class scan); above, a bitonic network with the boxes in LDS up to 4096
+    candidates and from the record table up to 8192 (nms.hip); the filter's 256-row groups end ragged (n % 256 != 0).  Same
+    rows as the oracle in every regime, and the second call on the same workspace (nothing is zeroed between calls) agrees
+    with the first."""
+    from realtimeobjectdetection_amd.util import write_results
+    p = synth.synth_predictions(3, n, ncls, 608, seed=n + int(obj_mu * 10), obj_mu=obj_mu, obj_sigma=1.0)
+    p[2, :, 4] *= 0.8                                          # third image: fewer candidates than the others
+    conf, thr = 0.5, 0.45
+    c0 = int((p[0, :, 4] > conf).sum())
+    assert lo <= c0 <= hi, c0
+    pg = torch.from_numpy(p).cuda()
+    r = write_results(pg, ncls, conf, thr)
+    want = O.write_results(torch.from_numpy(p), ncls, conf, thr)
+    assert np.array_equal(r.cpu().numpy(), want.numpy())
+    assert torch.equal(write_results(pg, ncls, conf, thr), r)
+
+
 def test_iou_and_confidence_mask(golden_dir):
     from realtimeobjectdetection_amd.util import bbox_iou, confidence_mask
     g = np.load(os.path.join(golden_dir, "iou.npz"))
