@@ -446,7 +446,7 @@ bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
 #define RTOD_BAND_TILES(X) \
     X(0, 128, 128, 4, 2, 4, 1, "") X(1, 128, 64, 4, 2, 4, 1, "") X(2, 192, 128, 4, 2, 3, 1, "") X(3, 192, 128, 6, 2, 3, 1, "") \
     X(4, 96, 128, 2, 4, 4, 1, "") X(5, 128, 128, 2, 2, 2, 1, "") X(6, 64, 128, 2, 4, 4, 1, "") \
-    X(7, 96, 128, 2, 4, 4, 2, ",k2") X(8, 128, 128, 4, 2, 4, 2, ",k2")
+    X(7, 96, 128, 2, 4, 4, 2, ",k2") X(8, 128, 128, 4, 2, 4, 2, ",k2") X(9, 64, 128, 2, 4, 4, 2, ",k2") X(10, 128, 64, 4, 2, 4, 2, ",k2")
 
 #define RTOD_X_INFO(mode, bm, bn, nwm, nwn, minw, kg, sfx) {bm, bn, "conv_band_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
 static const ConvVariantInfo kBandModes[BAND_MODES] = { RTOD_BAND_TILES(RTOD_X_INFO) };

@@ -134,8 +134,8 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 // A layer the band kernel supports ALWAYS runs on it (its split-K layers sum in a different order than the generic kernel, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
-constexpr int BAND_MODES = 9;              // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
-                                           // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2
+constexpr int BAND_MODES = 11;             // 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
+                                           // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2, 64x128/2x4, 128x64/4x2 (13x13 grids)
 constexpr int BAND_K2_MODE0 = 7;
 int conv_band_layer_kg(int cin, int h, int w);
 bool conv_band_mode_valid(int mode, int cin, int h, int w);
