@@ -38,13 +38,19 @@ _OVERFLOW_MSG = ("Darknet (precision f16s3): an activation reached the split-f16
 _pending_overflow = {}      # output data_ptr -> weakref(model): util.write_results reads the model's overflow flag at its host sync
 
 
-def check_overflow_for(prediction):
-    """Called by util.write_results after its host synchronisation: raises if the forward that produced this
-    prediction tensor saturated a split-f16 activation."""
+def take_pending_overflow(prediction):
+    """``(model, flag tensor)`` of the forward that produced ``prediction`` (or ``(None, None)``): util.write_results reads the
+    flag in the same host synchronisation as its detection counts instead of paying a second round trip."""
     ref = _pending_overflow.pop(prediction.data_ptr(), None)
     model = ref() if ref is not None else None
-    if model is not None:
-        model.check_overflow()
+    if model is None or model._ovf is None:
+        return None, None
+    return model, model._ovf
+
+
+def raise_overflow(model):
+    model._ovf.zero_()
+    raise FloatingPointError(_OVERFLOW_MSG)
 
 
 class EmptyLayer(nn.Module):

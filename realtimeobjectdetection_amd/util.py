@@ -138,6 +138,17 @@ def bbox_iou(box1: torch.Tensor, box2: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_host_cache = {}
+
+
+def _host_ints(dev):
+    """Pinned int32[4] per device: landing place of write_results' counts and the split-f16 range flag."""
+    h = _host_cache.get(dev.index)
+    if h is None:
+        h = _host_cache[dev.index] = torch.empty(4, dtype=torch.int32).pin_memory()
+    return h
+
+
 def _nms_buffers(dev, B, n, cap):
     key = (dev.index, B, n, cap)
     buf = _ws_cache.get(key)
@@ -201,10 +212,16 @@ def write_results(prediction, num_class, confidence=0.6, nms_conf=0.4):
     but none had a non-zero class score (what the reference's concatenation yields), or int ``0``."""
     B, n = prediction.size(0), prediction.size(1)
     out, counts = write_results_async(prediction, num_class, confidence, nms_conf)
-    c = counts[:2].tolist()                    # one host sync, like the reference's own .tolist()/nonzero
-    D, cand = int(c[0]), int(c[1])
-    from .darknet import check_overflow_for
-    check_overflow_for(prediction)             # split-f16 range guard of the forward that produced `prediction`
+    from .darknet import take_pending_overflow, raise_overflow
+    model, flag = take_pending_overflow(prediction)     # split-f16 range guard of the forward that produced `prediction`
+    host = _host_ints(prediction.device)
+    host[:2].copy_(counts[:2], non_blocking=True)
+    if flag is not None:
+        host[2:3].copy_(flag.reshape(-1)[:1], non_blocking=True)
+    torch.cuda.current_stream(prediction.device).synchronize()   # ONE host sync (counts + flag), like the reference's own .tolist()/nonzero
+    D, cand = int(host[0]), int(host[1])
+    if flag is not None and int(host[2]) != 0:
+        raise_overflow(model)
     if D > out.size(0):                        # more detections than the default capacity: redo at full size
         out, counts = write_results_async(prediction, num_class, confidence, nms_conf, cap=B * n)
         D = int(counts[0].item())
