@@ -70,6 +70,14 @@ __device__ unsigned long long g_band_real[STAMP_BLOCKS * STAMP_WAVES];     // s_
 #define RTOD_STAMP(i)
 #endif
 
+// Diagnostic build only (make timeline -> librtod_tl.so, -DRTOD_TIMELINE): start / end wall clock (s_memrealtime, 100 MHz), shader
+// cycles (s_memtime) and HW_ID of every workgroup of a launch — three clock reads per workgroup, nothing inside the loop —
+// summarised by the launcher: round structure, per-round workgroup durations, tail, the clock the chip held.
+#ifdef RTOD_TIMELINE
+constexpr int TL_BLOCKS = 2048;
+__device__ unsigned long long g_band_tl[TL_BLOCKS * 4];
+#endif
+
 constexpr int BAND_MAX_W = 94;
 // Epilogue flavour.  0 (default): pixel-major accumulators, LDS-transposed stores (256-byte runs per pixel).  1: transposed
 // product + register epilogue (conv_f16s3_epilogue_regs; 64-byte segments per pixel, no LDS pass) — bit-identical, measured
@@ -106,6 +114,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     constexpr int BSTAGE = 2 * PANEL_B;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef RTOD_TIMELINE
+    const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl_cstart_ = __builtin_amdgcn_s_memtime();
+#endif
     const int W = a.Wi, H = a.Hi;
     const int NBR = band_rows(BM, W);                          // band rows incl. padding; the zero row is row NBR
     const int plane = (NBR + 1) * 64;
@@ -257,13 +269,17 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     const int b_lane = (wn * WN + lr) * 64 + ((lh ^ band_swz(lr)) << 4);     // WN % 16 == 0: the row's swizzle is the lane's
     f16x8 ah[TM], al[TM];
+    // Branch-free: the offset of a valid tap and the zero row are merged by a bit select (bit `tap` of vmask, sign-extended,
+    // is the mask) — the divergent-branch form cost 6 registers and a basic-block split per 16-row tile.
+    const int lh4 = lh << 4;
     auto read_a = [&](int tap) {
         const int shift = (tap / 3) * W + (tap % 3);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = prow[i] + shift;
-            const bool ok = (vmask[i] >> tap) & 1u;
-            const int o = ok ? row * 64 + ((lh ^ band_swz(row)) << 4) : zero_off;
+            const int x = (row << 6) | (((row << 3) ^ lh4) & 0x30);          // row * 64 + ((lh ^ band_swz(row)) << 4)
+            const int sel = __builtin_amdgcn_sbfe((int)vmask[i], tap, 1);     // 0 or -1
+            const int o = (x & sel) | (zero_off & ~sel);
             ah[i] = *reinterpret_cast<const f16x8*>(bandh + o);
             al[i] = *reinterpret_cast<const f16x8*>(bandl + o);
         }
@@ -370,6 +386,15 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         g_band_real[blockIdx.x * STAMP_WAVES + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime() - rstart_;
     }
 #endif
+#ifdef RTOD_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < TL_BLOCKS) {
+        g_band_tl[blockIdx.x * 4] = tl_start_;
+        g_band_tl[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        g_band_tl[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
+        g_band_tl[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tl_cstart_;
+    }
+#endif
 }
 
 template <int BM, int BN, int NWM, int NWN, int MINW, int KG = 1>
@@ -400,6 +425,39 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
     }
     if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NWM * NWN * 64 * KG), lds, s, ax, gm, gn);
+#ifdef RTOD_TIMELINE
+    {   // diagnostic build: synchronises, prints the launch's workgroup timeline
+        static int printed = 0;
+        const int nb = gm * gn < TL_BLOCKS ? gm * gn : TL_BLOCKS;
+        if (printed < 60 && hipDeviceSynchronize() == hipSuccess) {
+            static unsigned long long h[TL_BLOCKS * 4];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_band_tl), sizeof(unsigned long long) * 4 * nb) == hipSuccess) {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                double cyc = 0, rt = 0;
+                for (int b = 0; b < nb; ++b) {
+                    if (h[b * 4] < t0) t0 = h[b * 4];
+                    if (h[b * 4 + 1] > t1) t1 = h[b * 4 + 1];
+                    cyc += (double)h[b * 4 + 3]; rt += (double)(h[b * 4 + 1] - h[b * 4]);
+                }
+                // first round = started within 2 us of the first start
+                double d1 = 0, d2 = 0, s2min = 1e9, s2max = 0, e1min = 1e9, e1max = 0; int n1 = 0, n2 = 0;
+                for (int b = 0; b < nb; ++b) {
+                    const double st = (h[b * 4] - t0) / 100.0, en = (h[b * 4 + 1] - t0) / 100.0;
+                    if (st < 2.0) { ++n1; d1 += en - st; if (en < e1min) e1min = en; if (en > e1max) e1max = en; }
+                    else { ++n2; d2 += en - st; if (st < s2min) s2min = st; if (st > s2max) s2max = st; }
+                }
+                fprintf(stderr, "[timeline] band<%d,%d,%dx%d,k%d> W=%d Cin=%d Cout=%d res=%d tiles=%d | span %.1f us | round 1: %d wgs, mean %.1f us, ends %.1f..%.1f | later: %d wgs, starts %.1f..%.1f, mean %.1f us | clock %.0f MHz\n",
+                        BM, BN, NWM, NWN, KG, a.Wi, a.Cin, a.Cout, a.res ? 1 : 0, gm * gn, (t1 - t0) / 100.0, n1, n1 ? d1 / n1 : 0.0, e1min, e1max, n2, n2 ? s2min : 0.0, n2 ? s2max : 0.0, n2 ? d2 / n2 : 0.0,
+                        rt > 0 ? cyc / rt * 100.0 : 0.0);
+                if (printed < 2) for (int b = 0; b < nb; b += 37) {
+                    const unsigned w = (unsigned)h[b * 4 + 2];
+                    fprintf(stderr, "[timeline]   wg %4d xcc %u se %u cu %2u tg %u  %.1f .. %.1f us\n", b, (unsigned)(h[b * 4 + 2] >> 32), (w >> 13) & 7, (w >> 8) & 15, (w >> 16) & 15, (h[b * 4] - t0) / 100.0, (h[b * 4 + 1] - t0) / 100.0);
+                }
+                ++printed;
+            }
+        }
+    }
+#endif
 #ifdef RTOD_STAMPS
     {   // print the mean cycles per phase over the first blocks' waves (diagnostic build: synchronises)
         static int printed = 0;
