@@ -109,7 +109,6 @@ int rtod_plan_set_precision(rtod_plan* plan, int mode);
  *   "ring_kernel"       persistent LDS-DMA ring tiles among the autotune candidates (bit-identical to the generic tiles)
  *   "patch_kernel"      2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers (bit-identical)
  *   "stem2_kernel"      layers 0-2 of Darknet-53 in one kernel (conv_stem2_f16s3.hip, bit-identical); 0: stand-alone kernels
- *   "pw_kernel"         (default 0) streaming kernel for the stand-alone 1x1 layers
  *   "bn_batch_stats"    (default 0) exact-fp32 plans: BatchNorm on batch statistics instead of the folded running statistics
  *   "k_slices"          exact-fp32 plans: deep small-grid layers summed in K slices (conv_igemm_f32.hip); 0: one chain
  *   "k_slice_workgroups" ... one workgroup per slice when the grid is small; 0: always inside the workgroup (same bits)

@@ -300,7 +300,6 @@ int Plan::set_option(const char* name, int value) {
     else if (k == "bn_batch_stats") flag = &opt_bn_batch_stats;
     else if (k == "k_slice_workgroups") flag = &opt_k_slice_workgroups;
     else if (k == "patch_kernel") flag = &opt_patch_kernel;
-    else if (k == "pw_kernel") flag = &opt_pw_kernel;
     else if (k == "stem_kernel") flag = &opt_stem_kernel;
     else if (k == "band_kernel") flag = &opt_band_kernel;
     else if (k == "fuse_shortcut") flag = &opt_fuse_shortcut;
@@ -559,10 +558,6 @@ void Plan::layout_weights() {
             pc.s_off = packed_floats; packed_floats += pc.Npad;
             pc.band = conv_band_supported(L.size, L.stride, L.pad, L.cin, L.win) && L.hout == L.hin &&
                       !(L.fused_into >= 0 && layers[L.fused_into].type == LT_YOLO) && opt_band_kernel;
-            // stand-alone 1x1 conv (no shortcut / decode in its epilogue, not hosted by the previous conv): streaming kernel
-            bool hosted = false;
-            for (const auto& l : launches) if (l.kind == LK_CONV && l.layer == pc.layer && l.pw_host >= 0 && opt_fuse_pointwise) hosted = true;
-            pc.pw = opt_pw_kernel && !hosted && L.fused_into < 0 && L.act <= 1 && conv_pw_supported(L.size, L.stride, L.pad, L.cin, L.cout);
         } else {
             pc.w_off = packed_floats; packed_floats += panel;
             // deep small-grid layers (13x13 ... 52x52 stages, K >= 256): the K sum is formed in slices of 9 chunks (one 3x3 tap
@@ -805,15 +800,11 @@ int Plan::f32_slice_mode(const Launch& l, int batch, int variant) const {
 
 int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const {
     if (v >= PATCH_VARIANT_BASE) {
-        if (pc.band || pc.pw) { set_error("patch variant requested for a band / pointwise layer"); return RTOD_E_STATE; }
+        if (pc.band) { set_error("patch variant requested for a band layer"); return RTOD_E_STATE; }
         return launch_conv_patch_f16s3(a, v - PATCH_VARIANT_BASE, s);
     }
-    if (v >= PW_VARIANT_BASE) {
-        if (!pc.pw) { set_error("pointwise variant requested for a layer that is not a stand-alone 1x1 conv"); return RTOD_E_STATE; }
-        return launch_conv_pw_f16s3(a, v - PW_VARIANT_BASE, s);
-    }
     if (v >= RING_VARIANT_BASE) {
-        if (pc.band || pc.pw) { set_error("ring variant requested for a band / pointwise layer"); return RTOD_E_STATE; }
+        if (pc.band) { set_error("ring variant requested for a band layer"); return RTOD_E_STATE; }
         return launch_conv_ring_f16s3(a, v - RING_VARIANT_BASE, s);
     }
     if (v >= BAND_VARIANT_BASE) {
@@ -897,8 +888,6 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     std::vector<int> cand;
     if (convs[l.conv_slot].band) {                                                    // band layers: band tiles only (see rtod_internal.h)
         for (int m = 0; m < BAND_MODES; ++m) if (conv_band_mode_valid(m, L.cin, L.hin, L.win)) cand.push_back(BAND_VARIANT_BASE + m);
-    } else if (convs[l.conv_slot].pw) {                                               // pointwise layers: their own kernel, slice width tuned
-        for (int m = 0; m < PW_MODES; ++m) if (conv_pw_mode_valid(m, L.cin, L.cout)) cand.push_back(PW_VARIANT_BASE + m);
     } else {
         for (int v = 0; v < HV_COUNT; ++v) {
             const ConvVariantInfo& vi = conv_f16s3_variant_info(v);
@@ -965,24 +954,6 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
 
 int Plan::variant_for(const Launch& l, int batch) const {
     const bool band = convs[l.conv_slot].band;
-    const Layer& PL = layers[l.layer];
-    auto pw_default = [&]() {                                // widest slice that is valid and still gives >= 128 workgroups
-        int best = -1;
-        for (int m = 0; m < PW_MODES; ++m) if (conv_pw_mode_valid(m, PL.cin, PL.cout)) {
-            const int64_t wgs = (((int64_t)batch * PL.hout * PL.wout + 191) / 192) * (PL.cout / (32 << m));
-            if (best < 0 || wgs >= 128) best = m;
-        }
-        return PW_VARIANT_BASE + best;
-    };
-    if (convs[l.conv_slot].pw) {
-        if (opt_force_f16s3_variant >= PW_VARIANT_BASE && conv_pw_mode_valid(opt_force_f16s3_variant - PW_VARIANT_BASE, PL.cin, PL.cout)) return opt_force_f16s3_variant;
-        if (opt_force_f16s3_variant < 0) {
-            auto itp = tuned.find(batch);
-            const size_t idxp = &l - &launches[0];
-            if (itp != tuned.end() && idxp < itp->second.size() && itp->second[idxp] >= 0) return itp->second[idxp];
-        }
-        return pw_default();
-    }
     if (opt_force_f16s3_variant >= 0) {                      // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others
         const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];

@@ -65,7 +65,6 @@ struct PackedConv {
     bool stem = false;                // conv_stem.hip: weights [28][Cout] fp32, or (split) [Cout][32] f16 hi / lo planes + inv_scale
     bool split = false;               // f16 hi/lo planes (conv_igemm_f16s3) instead of an fp32 panel
     bool band = false;                // eligible for conv_band_f16s3 (3x3 s1 p1, band fits LDS)
-    bool pw = false;                  // runs on conv_pw_f16s3 (stand-alone 1x1 conv, no residual / decode epilogue)
     int64_t wl_off = 0, s_off = 0;    // split: w_off = hi plane, wl_off = lo plane (float units), s_off = inv_scale
     int64_t stats_off = -1;           // batch-statistics BatchNorm plans: this layer's [Npad] mean, [Npad] variance in Plan::d_bn_stats (doubles)
     int64_t bn_off = 0;               // batch-statistics BatchNorm plans: [Npad] beta, [Npad] gamma (the conv itself is packed unfolded)
@@ -98,8 +97,6 @@ struct Plan {
     bool opt_fuse_pointwise = true;   // run a 1x1 conv in the previous conv's epilogue where the plan allows it
     bool opt_stem_kernel = true;      // dedicated NCHW-reading kernel for layer 0 (else pack + generic conv)
     bool opt_band_kernel = true;      // LDS-band kernel for the 3x3 stride-1 layers it supports
-    bool opt_pw_kernel = false;       // streaming kernel for the stand-alone 1x1 layers it supports (measured slower than the LDS-tiled kernels on the
-                                      // pixel-major activation layout: 64-byte half-line loads; kept as an option)
     bool opt_bn_batch_stats = false;  // exact-fp32 plans: BatchNorm on the statistics of the batch (what the reference runs: no .eval()), not folded
     bool opt_k_slices = true;         // exact-fp32 kernels: deep small-grid layers summed in K slices (own workgroups when the grid is small)
     bool opt_k_slice_workgroups = true;   // ... (off: always the in-workgroup schedule — same bits; A/B and tests)

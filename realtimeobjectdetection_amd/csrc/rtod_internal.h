@@ -168,16 +168,6 @@ bool conv_patch_supported(int ksize, int stride, int pad, int cin, int cout);
 const ConvVariantInfo& conv_patch_mode_info(int mode);
 int conv_patch_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_patch_f16s3(const ConvArgs& a, int mode, hipStream_t s);
-// Barrier-free streaming kernel for 1x1 convolutions (conv_pw_f16s3.hip): weights resident in LDS, activations straight
-// to registers.  A layer it supports always runs on it (its bits differ from the LDS-tiled kernels': swapped MFMA operands);
-// the modes (BN = 32 / 64 / 128 output channels per workgroup) agree bitwise.
-constexpr int PW_MODES = 3;
-constexpr int PW_VARIANT_BASE = 90;        // variant ids >= this: PW_VARIANT_BASE + mode
-bool conv_pw_supported(int ksize, int stride, int pad, int cin, int cout);
-bool conv_pw_mode_valid(int mode, int cin, int cout);
-const ConvVariantInfo& conv_pw_mode_info(int mode);
-int conv_pw_kernel_name(int mode, int cin, char* buf, size_t len);
-int launch_conv_pw_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 
 int launch_conv_stem(const float* x_nchw, const float* w, const float* bias, const View& out, int B, int H, int W,
                      int Ho, int Wo, int stride, int Cout, int leaky, hipStream_t s);

@@ -271,3 +271,46 @@ def test_plan_options_are_explicit_state_not_environment(monkeypatch):
     assert {3, 4, 5, 6} <= {li.kind for li in kinds(h)}
     assert lib.rtod_plan_set_precision(h, 1) == -3
     lib.rtod_plan_destroy(h)
+
+
+def test_launch_kernel_names_have_the_format_rocprofv3_prints():
+    """rtod_plan_launch_kernel_name feeds every name-keyed join of bench.py / tools (per-kernel roofline, HBM-traffic lookup):
+    each name must be the demangled instantiation name rocprofv3 prints for that kernel family.  Checked against the name
+    column of the committed profiles/r0*_kernel_stats.csv (numbers masked: same family, same template arity, same argument
+    list), for the heuristic YOLOv3 608 plan and with the patch tiles forced (round 2 labelled variant 214, the weights-resident
+    patch kernel, as a kernel of another family)."""
+    import csv, glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mask = lambda n: re.sub(r"\d+", "N", n)
+    known = set()
+    for f in glob.glob(os.path.join(root, "profiles", "r0*_kernel_stats.csv")):
+        for row in csv.DictReader(open(f)):
+            known.add(mask(row["Name"]))
+    assert any(mask("conv_band_f16s3_kernel") in k for k in known) and any(mask("conv_patch_wres_f16s3_kernel") in k for k in known)
+    lib = _ffi.lib()
+    family = {range(100, 150): "conv_igemm_f16s3_kernel", range(150, 170): "conv_band_f16s3_kernel", range(170, 190): "conv_ring_f16s3_kernel",
+              range(210, 214): "conv_patch_f16s3_kernel", range(214, 215): "conv_patch_wres_f16s3_kernel", range(230, 231): "conv_stem2_f16s3_kernel"}
+    seen = set()
+    for force in (-1, 114, 112, 72):
+        rc, h = _plan(cfgs.yolov3_cfg(), 608)
+        assert rc == 0
+        if force >= 0:
+            assert lib.rtod_plan_set_option(h, b"force_f16s3_variant", force) == 0, _ffi.last_error()
+        assert lib.rtod_plan_set_precision(h, 1) == 0, _ffi.last_error()
+        info = _ffi.PlanInfo()
+        assert lib.rtod_plan_get_info(h, C.byref(info)) == 0
+        for i in range(info.n_launches):
+            li = _ffi.LaunchInfo()
+            assert lib.rtod_plan_get_launch(h, i, C.byref(li)) == 0
+            buf = C.create_string_buffer(256)
+            assert lib.rtod_plan_launch_kernel_name(h, i, buf, 256) == 0, _ffi.last_error()
+            name = buf.value.decode()
+            if li.kind != 0 or li.flops_per_frame == 0:
+                assert name == ""
+                continue
+            fam = [v for k, v in family.items() if li.variant in k]
+            assert fam and ("rtod::" + fam[0] + "<") in name, (li.layer, li.variant, name)
+            assert mask(name) in known, (li.layer, li.variant, name)
+            seen.add(fam[0])
+        lib.rtod_plan_destroy(h)
+    assert {"conv_band_f16s3_kernel", "conv_patch_wres_f16s3_kernel", "conv_patch_f16s3_kernel", "conv_ring_f16s3_kernel", "conv_stem2_f16s3_kernel"} <= seen

@@ -372,6 +372,64 @@ def test_v5_style_blocks_vs_torch_ops(tmp_path_factory, precision, res, B):
         assert_detections_equivalent(dg.cpu().numpy(), dw.numpy(), 0.6, 0.5)
 
 
+# ------------------------------------------------------------------------------- as-run BatchNorm (training mode)
+@pytest.mark.parametrize("net,res,B", [("yolov3-tiny", 416, 2), ("yolov3", 416, 2), ("yolov3", 320, 3)])
+def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path_factory, net, res, B):
+    """The reference's callers never call .eval() (detect.py:185-194): nn.BatchNorm2d then normalises with
+    the statistics of the batch (src/darknet.py:493-495).  A Darknet left in training mode — what the two-import-line drop-in
+    of INTEGRATION.md section 1 runs — does exactly that (exact-fp32 kernels: raw conv -> per-channel mean / biased variance
+    in double -> normalise + leaky + shortcut): output against the REAL reference run in training mode
+    (tests/golden/make_golden_trainbn.py), running_mean / running_var updated like torch updates them, and the result
+    depends on the batch (which is why eval mode is the canonical, shardable path).
+
+    TOLERANCE OF THIS MODE (stated in DESIGN.md section 1 and INTEGRATION.md section 1): 99.9 % of the output within the
+    path's 1e-4, maximum within 5e-4.  Evidence, profiles/r03_trainbn_floor.json (tools/trainbn_floor.py, CPU only): the
+    reference's own float32 evaluation of this mode sits 1.4-1.5e-4 (max) from the float64 evaluation of the same graph —
+    16x its eval-mode distance (9e-6) — and moves by 4e-5 when only its thread count changes; normalising by the statistics
+    of 300-340 samples per channel on the 13x13 / 10x10 grids amplifies the convolutions' rounding layer by layer
+    (profiles/r03_trainbn_layers.json: GPU vs oracle per layer, both modes).  No float32 implementation can promise 1e-4
+    on every element against another one here; the test gates the bulk at 1e-4 and bounds the tail."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    g = np.load(os.path.join(golden_dir, "trainbn.npz"))
+    tag = "%s_%d_b%d" % (net, res, B)
+    cfg_text = NETS[net]()
+    d = tmp_path_factory.mktemp("trainbn_" + tag)
+    m = Darknet(cfgs.write_cfg(str(d / (net + ".cfg")), cfg_text), True)          # no .eval(): as detect.py builds it
+    assert m.training
+    m.net_info["height"] = res
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    m.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=31))
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="training mode"):
+        y = m(x.cuda())
+    assert m.active_precision == "fp32"
+    stride = int(g["stride_" + tag])
+    got = y.cpu().numpy()[:, ::stride]
+    e = rel_err(got, g["rows_" + tag])
+    assert np.quantile(e, 0.999) <= TOL and e.max() <= 5e-4, (float(np.quantile(e, 0.999)), float(e.max()))
+    # side effect on the module buffers (momentum 0.1, unbiased variance), first and last BatchNorm layer
+    bns = [(i, mod) for i, seq in enumerate(m.module_list) for mod in seq.children() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for i, bn in (bns[0], bns[-1]):
+        assert np.allclose(bn.running_mean.cpu().numpy(), g["rmean_%s_L%d" % (tag, i)], rtol=1e-4, atol=1e-6)
+        assert np.allclose(bn.running_var.cpu().numpy(), g["rvar_%s_L%d" % (tag, i)], rtol=1e-4, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+    # batch-dependence: the same frame alone gives different rows (unlike eval mode, where they are bit-identical)
+    m.update_running_stats = False
+    with torch.no_grad():
+        y1 = m(x[:1].cuda())
+    assert not torch.equal(y1[0], y[0])
+    # ... and eval() afterwards is the folded fast path again, with the statistics the training-mode forward left behind
+    m.eval()
+    with torch.no_grad():
+        ye = m(x.cuda())
+    assert torch.isfinite(ye).all() and not torch.equal(ye, y)
+    m.precision = "f16s3"
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(x.cuda())
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("res,B", [(320, 2), (640, 1)])
 def test_yolov5s_style_graph_vs_torch_ops(tmp_path_factory, res, B, precision):
@@ -825,9 +883,8 @@ def test_forward_is_capturable_after_autotune(tmp_path_factory):
 def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     """Autotune may pick any tile of a kernel family for a layer, per batch size: every candidate must produce the same
     bits (same K order, same MFMA shape).  Forces each split-f16 tile variant in turn (generic implicit-GEMM tiles 0-11
-    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-60 on the band layers, slice widths
-    90-92 of the streaming kernel on the stand-alone 1x1 layers, 2-D patch tiles 110-114 on the wide 3x3 layers) — this also
-    launches every instantiation, including the ones autotune rarely picks."""
+    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-60 on the band layers, 2-D patch tiles
+    110-114 on the wide 3x3 layers) — this also launches every instantiation, including the ones autotune rarely picks."""
     from realtimeobjectdetection_amd.darknet import Darknet
     res = 416
     cfg_text = NETS["yolov3"]()
@@ -836,9 +893,8 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
     x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
     ref = None
-    for v in list(range(12)) + list(range(50, 61)) + list(range(70, 78)) + [90, 91, 92] + list(range(110, 115)):
+    for v in list(range(12)) + list(range(50, 61)) + list(range(70, 78)) + list(range(110, 115)):
         m = Darknet(cfg_path, True).eval()
-        m.options["pw_kernel"] = 1                             # 90-92: slice widths of the optional streaming 1x1 kernel
         m.net_info["height"] = res
         m.precision = "f16s3"
         m.autotune = False
