@@ -103,6 +103,9 @@ def test_detector_driver_end_to_end(tmp_path):
     metrics = det()
     saved = json.load(open(tmp_path / "det" / "metrics.json"))
     assert set(saved) == set(arrays) and saved == metrics
+    # schema of the fixture the reference holds (det/metrics.json -> tests/golden/metrics_schema.json)
+    from metrics_schema import validate_metrics
+    validate_metrics(saved, sorted(arrays), 80, 0.5, 416)
     for name in arrays:
         assert os.path.exists(tmp_path / "det" / ("det_yolov3-tiny_" + name))
     m = Darknet(cfg_path, True).eval()
@@ -169,3 +172,19 @@ def test_bench_self_launch_starts_ranks_without_touching_the_gpu_in_the_parent()
     assert r.returncode != 0
     assert r.stderr.count("needs a GPU") >= 1 and "rank" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_reference_held_metrics_fixture_satisfies_the_schema_rules():
+    """The validator the driver test uses is itself checked against the fixture the reference holds (det/metrics.json copied as
+    data into tests/golden/metrics_schema.json): 11 images, 32 rows of 8 floats, scream.jpg -> 0, column 0 = processing order."""
+    from metrics_schema import load_schema, validate_metrics
+    s = load_schema()
+    ref = s["reference_metrics"]
+    assert s["n_images"] == 11 == len(ref) and s["n_rows"] == 32 and ref["scream.jpg"] == 0
+    validate_metrics(ref, s["processing_order"], 80, 0.6, 416, s)
+    bad = json.loads(json.dumps(ref)); bad["dog.jpg"][0][0] += 1.0
+    with pytest.raises(AssertionError):
+        validate_metrics(bad, s["processing_order"], 80, 0.6, 416, s)
+    bad = json.loads(json.dumps(ref)); bad["scream.jpg"] = []
+    with pytest.raises(AssertionError):
+        validate_metrics(bad, s["processing_order"], 80, 0.6, 416, s)
