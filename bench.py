@@ -64,6 +64,13 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="plan option (rtod_plan_set_option) for A/B runs, e.g. --opt k_slices=0; recorded in config.plan_options")
     ap.add_argument("--layers-out", default="", help="write the per-launch table (JSON) here")
+    ap.add_argument("--tiles", default="", metavar="FILE",
+                    help="tile table (JSON): if FILE holds a table for this resolution / batch it is installed (rtod_plan_set_tiles: no autotune "
+                         "launches, the same kernels in every process — profiled passes replay the timing pass); otherwise autotune runs and "
+                         "its table is written there")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra workloads reported beside the headline (BASELINE configs[1]: YOLOv3 416x416 batch 8; configs[4]'s "
+                         "shape: the YOLOv5s-style graph 640x640 batch 8, parity unpinned)")
     return ap.parse_args(argv)
 
 
@@ -148,9 +155,10 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=14.0):
-    """Oracle forward and write_results on the host cores, bounded: all cores on the bench batch
-    (1 warm-up, up to 10 timed iterations inside ``budget_s``) and one thread on a single frame."""
+def cpu_baseline(cfg_text, w, res, batch, conf, nms, warmup=3, iters=10):
+    """Oracle forward and write_results on the host cores, BASELINE.md §4's protocol: 3 warm-up + 10 timed iterations of the
+    bench batch on this job's share of the host cores (forward and write_results timed separately), then one thread on a
+    single frame (1 warm-up + 3 timed).  About 25-30 s of CPU work on a 16-core share."""
     import torch
     from realtimeobjectdetection_amd import synth
     from oracle import darknet_ref as O
@@ -158,13 +166,10 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=14.0):
     ref = O.RefDarknet(cfg_text, res)
     ref.load_weight_stream(w)
     x = torch.from_numpy(synth.synth_frames(batch, res))
-    out = {}
     with torch.no_grad():
         torch.set_num_threads(cores)
-        t0 = time.perf_counter()
-        y = ref.forward(x)                      # warm-up (also sizes the sample)
-        warm = time.perf_counter() - t0
-        iters = int(max(1, min(10, budget_s // max(warm, 1e-3))))
+        for _ in range(warmup):
+            O.write_results(ref.forward(x), 80, conf, nms)
         tf = tn = 0.0
         for _ in range(iters):
             t0 = time.perf_counter()
@@ -174,19 +179,24 @@ def cpu_baseline(cfg_text, w, res, batch, conf, nms, budget_s=14.0):
             t2 = time.perf_counter()
             tf += t1 - t0; tn += t2 - t1
         out = {"value": round(batch * iters / (tf + tn), 3), "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": "%d x (yolov3 %dx%d batch %d forward + write_results) after 1 warm-up, torch %s CPU ops, %d threads"
-                         % (iters, res, res, batch, torch.__version__, cores),
+               "sample": "%d warm-up + %d timed x (yolov3 %dx%d batch %d forward + write_results), torch %s CPU ops, %d threads = this job's "
+                         "share of the host's cores (affinity / cgroup quota / the pool's 16 cores per GPU; %s visible)"
+                         % (warmup, iters, res, res, batch, torch.__version__, cores, os.cpu_count()),
                "forward_s_per_batch": round(tf / iters, 4), "write_results_s_per_batch": round(tn / iters, 4),
                "cpu_model": cpu_model_name(), "host_cores_visible": os.cpu_count()}
         torch.set_num_threads(1)
         x1 = x[:1].contiguous()
-        t0 = time.perf_counter()
-        y1 = ref.forward(x1)
-        t1 = time.perf_counter()
-        O.write_results(y1, 80, conf, nms)
-        t2 = time.perf_counter()
-        out["one_thread"] = {"value": round(1.0 / (t2 - t0), 4), "unit": "frames/s", "forward_s": round(t1 - t0, 4),
-                             "write_results_s": round(t2 - t1, 4), "sample": "1 x (batch 1 forward + write_results), 1 thread, no warm-up"}
+        O.write_results(ref.forward(x1), 80, conf, nms)             # warm-up
+        tf = tn = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y1 = ref.forward(x1)
+            t1 = time.perf_counter()
+            O.write_results(y1, 80, conf, nms)
+            t2 = time.perf_counter()
+            tf += t1 - t0; tn += t2 - t1
+        out["one_thread"] = {"value": round(3.0 / (tf + tn), 4), "unit": "frames/s", "forward_s": round(tf / 3, 4),
+                             "write_results_s": round(tn / 3, 4), "sample": "1 warm-up + 3 timed x (batch 1 forward + write_results), 1 thread"}
         torch.set_num_threads(cores)
     return out
 
@@ -250,6 +260,96 @@ def roofline_from_launches(model, x, steps):
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(pw_bytes / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pw_ms > 0 else None}}
     return roof, per_layer, groups
+
+
+# ------------------------------------------------------------------------------------------ extra workloads (N = 1)
+def _throughput(models, x, post, steps, warmup):
+    """frames/s of forward + post over `steps` steps, batches alternating over `models` (one HIP stream each), `post` on a side
+    stream behind an event — the schedule of the headline figure; device-synchronise on both sides of the timed region."""
+    import torch
+    dev = x.device
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in models[1:]]
+    side = torch.cuda.Stream(device=dev)
+
+    def step(i):
+        k = i % len(models)
+        with torch.no_grad(), torch.cuda.stream(streams[k]):
+            y = models[k](x)
+            side.wait_stream(streams[k])
+            with torch.cuda.stream(side):
+                post(y)
+            y.record_stream(side)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return round(x.size(0) * steps / dt, 2), round(dt / steps * 1e3, 4)
+
+
+def extra_workloads(dev, args):
+    """The other single-GPU configurations BASELINE.json lists, measured in this run beside the headline: configs[1] (YOLOv3
+    416x416 batch 8) and configs[4]'s SHAPE (YOLOv5s-style graph 640x640 batch 8 reusing the conv / NMS kernels; the reference
+    fetches that model from the network, detect.py:255-285 — here: published architecture restated, synthetic weights, PARITY
+    UNPINNED).  Same schedule as the headline (two batches in flight) and the strictly sequential figure."""
+    import torch
+    from realtimeobjectdetection_amd import cfgs, synth
+    from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd.util import write_results_async, nms_class_offset_async
+    out = {}
+    B = 8
+    # -- configs[1]
+    ms_ = [build_model(416, dev, B, args.precision)[0] for _ in range(2)]
+    for m_ in ms_:
+        m_.overflow_check = "off"
+    x = torch.from_numpy(synth.synth_frames(B, 416)).to(dev)
+    with torch.no_grad():
+        for m_ in ms_:
+            m_(x)
+    post = lambda y: write_results_async(y, 80, args.conf, args.nms, cap=4096)
+    v2, t2 = _throughput(ms_, x, post, args.steps, args.warmup)
+    v1, t1 = _throughput(ms_[:1], x, post, args.steps, args.warmup)
+    ir = build_ir(parse_cfg_text(cfgs.yolov3_cfg()), 416)
+    out["yolov3_416_b8"] = {"workload": "YOLOv3 cfg 416x416 batch=8, 1 GPU (BASELINE configs[1])", "value": v2, "unit": "frames/s", "ms_per_step": t2,
+                            "single_stream": {"value": v1, "ms_per_step": t1}, "precision": args.precision,
+                            "conv_gflop_per_frame": round(ir.conv_flops / 1e9, 3), "whole_path_tflops": round(v2 * ir.conv_flops / 1e12, 2),
+                            "f16_range_overflow": bool(any(m_.overflowed() for m_ in ms_))}
+    del ms_
+    # -- configs[4]'s shape
+    text = cfgs.yolov5s_style_cfg()
+    ir5 = build_ir(parse_cfg_text(text), 640)
+    w5 = synth.synth_weights(ir5)
+    ms_ = []
+    with tempfile.TemporaryDirectory() as d:
+        for _ in range(2):
+            m_ = Darknet(cfgs.write_cfg(os.path.join(d, "v5s.cfg"), text), True).eval()
+            m_.net_info["height"] = 640
+            m_.precision = "auto" if args.precision == "f16s3" else "fp32"
+            m_.overflow_check = "off"
+            m_.load_weight_stream(w5)
+            ms_.append(m_)
+    x = torch.from_numpy(synth.synth_frames(B, 640)).to(dev)
+    with torch.no_grad():
+        for m_ in ms_:
+            y = m_(x)
+    # synthetic weights leave obj * cls far below the usual 0.25: threshold = what ~1 % of the rows pass (~250 candidates per image)
+    score = (y[..., 4] * y[..., 5:].max(-1).values).flatten()
+    conf5 = float(torch.quantile(score[:: max(1, score.numel() // 100000)], 0.99))
+    post = lambda y: nms_class_offset_async(y, 80, conf5, 0.45, cap=4096)
+    v2, t2 = _throughput(ms_, x, post, args.steps, args.warmup)
+    v1, t1 = _throughput(ms_[:1], x, post, args.steps, args.warmup)
+    out["yolov5s_style_640_b8"] = {"workload": "YOLOv5s-SHAPED graph 640x640 batch=8 (BASELINE configs[4]'s shape): published v6.0 architecture restated in the "
+                                               "cfg grammar, synthetic weights, class-offset batched NMS; PARITY UNPINNED (the reference fetches its model "
+                                               "from torch.hub, detect.py:255-285: nothing to pin offline) - a workload of that shape for the kernels, not the reference's model",
+                                   "value": v2, "unit": "frames/s", "ms_per_step": t2, "single_stream": {"value": v1, "ms_per_step": t1},
+                                   "precision": ms_[0].active_precision, "conv_gflop_per_frame": round(ir5.conv_flops / 1e9, 3),
+                                   "whole_path_tflops": round(v2 * ir5.conv_flops / 1e12, 2), "conf_threshold_used": round(conf5, 5),
+                                   "f16_range_overflow": bool(any(m_.overflowed() for m_ in ms_))}
+    return out
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -344,10 +444,23 @@ def run_rank(args):
             dt = float(t.item())
         return dt, out
 
+    tiles_key = "%s_%d_b%d" % (args.precision, R, B)
+    tiles_src = "autotune (this run)"
+    if args.tiles and os.path.exists(args.tiles) and args.precision == "f16s3":
+        table = json.load(open(args.tiles)).get(tiles_key)
+        if table is not None:
+            for m_ in models:
+                m_.set_tiles(B, table)                  # no autotune launches: every process runs exactly these kernels
+            tiles_src = "installed from " + os.path.basename(args.tiles)
     with torch.no_grad():                               # set-up, not a step: every plan's first forward autotunes its tiles
         for m_ in models:
             m_(x)
     torch.cuda.synchronize()
+    if args.tiles and rank == 0 and args.precision == "f16s3" and tiles_src.startswith("autotune"):
+        tabs = json.load(open(args.tiles)) if os.path.exists(args.tiles) else {}
+        tabs[tiles_key] = model.get_tiles(B)
+        os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
+        json.dump(tabs, open(args.tiles, "w"))
     dt, (y, rows, counts) = timed_run(step, len(models))
     n_det, n_cand = [int(v) for v in counts[:2].tolist()]
     gathered = None
@@ -378,24 +491,33 @@ def run_rank(args):
     roof = None
     if rank == 0 and not args.no_roofline:
         roof, per_layer, groups = roofline_from_launches(model, x, max(1, min(args.steps, 10)))
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/traffic.json,
-        # written by tools/summarize_profiles.py: 2*FETCH_SIZE + WRITE_SIZE); null if it was not profiled
+        # HBM bytes per launch of that kernel: PMC counters need rocprofv3 around the process, so this run cannot measure them;
+        # the figure comes from the committed passes of this same command with the tile table frozen (profiles/traffic.json,
+        # tools/profile_round.sh + summarize_profiles.py: 2*FETCH_SIZE + WRITE_SIZE per launch, equal launch counts in both
+        # passes); null for a kernel / workload that was not profiled
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path) and R == 608 and B == 8:
             try:
-                roof["traffic"] = json.load(open(tr_path)).get(roof["kernel"])
+                tr = json.load(open(tr_path))
+                roof["traffic"] = tr.get("kernels", tr).get(roof["kernel"])
+                roof["traffic_source"] = tr.get("source", "profiles/traffic.json (rocprofv3 --pmc passes, not this run)")
             except Exception:
                 pass
         if args.layers_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.layers_out)), exist_ok=True)
             json.dump({"per_launch": per_layer, "groups": groups}, open(args.layers_out, "w"), indent=1)
+    n_inflight = len(models)
+    other = None
+    if rank == 0 and world == 1 and not args.no_extras and R == 608 and B == 8:
+        del extra, models[1:]                           # their arenas are not needed any more
+        other = extra_workloads(dev, args)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg_text, w, R, B, args.conf, args.nms)
 
     if rank == 0:
-        sched = ("%d batches in flight, write_results_async on %s" % (len(models), "the forward's stream" if args.serial_nms else "a second stream")
-                 if len(models) > 1 else "one batch in flight, write_results_async")
+        sched = ("%d batches in flight, write_results_async on %s" % (n_inflight, "the forward's stream" if args.serial_nms else "a second stream")
+                 if n_inflight > 1 else "one batch in flight, write_results_async")
         line = {
             "metric": "frames/sec YOLOv3 %dx%d bs=%d (Darknet.forward + write_results; %s)" % (R, R, B, sched),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -403,9 +525,9 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x2-split (3 MFMA products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "YOLOv3 cfg %dx%d batch=%d per GPU, %s MFMA conv + fused head + GPU NMS (BASELINE configs[%d])"
                                    % (R, R, B, "exact-fp32" if args.precision == "fp32" else "split-f16", 2 if R == 608 else 1),
-                       "precision": args.precision, "plan_options": plan_opts,
+                       "precision": args.precision, "plan_options": plan_opts, "tiles": tiles_src,
                        "frames_per_step": world * B, "parallelism": "frame-shard x%d" % world,
-                       "in_flight_batches": len(models), "write_results": "async (device-side counts, capacity %d rows)" % CAP,
+                       "in_flight_batches": n_inflight, "write_results": "async (device-side counts, capacity %d rows)" % CAP,
                        "write_results_stream": "same" if args.serial_nms else "second stream",
                        "conf": args.conf, "nms": args.nms, "detections_last_step": n_det, "candidates_last_step": n_cand,
                        "f16_range_overflow": bool(overflow),
@@ -420,6 +542,8 @@ def run_rank(args):
         line["dropin_api"] = dropin
         if roof is not None:
             line["roofline"] = roof
+        if other is not None:
+            line["other_configs"] = other
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -138,6 +138,13 @@ int rtod_forward(rtod_plan* plan, const float* x_dev, int batch, float* out_dev,
  * Synchronises `stream` repeatedly; not capturable.  No-op (plain forward) for exact-fp32 plans.  Tile choice never
  * changes results: every candidate of a layer sums its K products in the same order. */
 int rtod_plan_autotune(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream);
+/* The tile table of a batch size: one variant id per launch (-1: heuristic / not a split-f16 conv).  get: copies the table an
+ * autotune run left (returns the number of launches, or RTOD_E_STATE if that batch size was never tuned; `variants` may be NULL
+ * to ask for the count).  set: installs a table (e.g. one saved by an earlier process) so that later forwards of that batch size
+ * launch exactly those kernels without measuring anything — profiled passes (rocprofv3 --pmc) then replay the launches of the
+ * timing pass.  Every entry is checked against its layer (band tiles on band layers, valid split-K mode, ...): RTOD_E_ARG. */
+int rtod_plan_get_tiles(const rtod_plan* plan, int batch, int* variants, int capacity);
+int rtod_plan_set_tiles(rtod_plan* plan, int batch, const int* variants, int count);
 /* Same, with a hipEvent pair around every launch (recorded on `stream`); synchronises and
  * writes the per-launch durations in ms to launch_ms[n_launches] (host).  For bench/roofline. */
 int rtod_forward_timed(rtod_plan* plan, const float* x_dev, int batch, float* out_dev,

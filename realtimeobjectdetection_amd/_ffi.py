@@ -49,6 +49,8 @@ SIGNATURES = {
     "rtod_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rtod_plan_set_overflow_flag": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtod_plan_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "rtod_plan_get_tiles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "rtod_plan_set_tiles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "rtod_plan_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rtod_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rtod_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

@@ -176,6 +176,25 @@ int rtod_plan_autotune(rtod_plan* plan, const float* x_dev, int batch, float* ou
     RTOD_GUARD_END
 }
 
+int rtod_plan_get_tiles(const rtod_plan* plan, int batch, int* variants, int capacity) {
+    if (!plan) { set_error("get_tiles: null plan"); return RTOD_E_ARG; }
+    auto it = plan->p.tuned.find(batch);
+    if (it == plan->p.tuned.end()) { set_error("get_tiles: batch %d has no tile table (run rtod_plan_autotune first)", batch); return RTOD_E_STATE; }
+    const int n = (int)it->second.size();
+    if (variants) {
+        if (capacity < n) { set_error("get_tiles: capacity %d < %d launches", capacity, n); return RTOD_E_ARG; }
+        for (int i = 0; i < n; ++i) variants[i] = it->second[i];
+    }
+    return n;
+}
+
+int rtod_plan_set_tiles(rtod_plan* plan, int batch, const int* variants, int count) {
+    RTOD_GUARD_BEGIN
+    if (!plan) { set_error("set_tiles: null plan"); return RTOD_E_ARG; }
+    return plan->p.set_tiles(batch, variants, count);
+    RTOD_GUARD_END
+}
+
 int rtod_forward_timed(rtod_plan* plan, const float* x_dev, int batch, float* out_dev, void* stream, float* launch_ms) {
     RTOD_GUARD_BEGIN
     if (!plan || !launch_ms) { set_error("forward_timed: null pointer"); return RTOD_E_ARG; }

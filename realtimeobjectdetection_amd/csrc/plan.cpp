@@ -952,6 +952,28 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     return RTOD_OK;
 }
 
+int Plan::set_tiles(int batch, const int* variants, int count) {
+    if (!variants || count != (int)launches.size() || batch <= 0 || batch > max_batch) { set_error("set_tiles: %d entries for %d launches, batch %d", count, (int)launches.size(), batch); return RTOD_E_ARG; }
+    if (precision != 1) { set_error("set_tiles: split-f16 plans only"); return RTOD_E_STATE; }
+    for (int i = 0; i < count; ++i) {
+        const int v = variants[i];
+        const Launch& l = launches[i];
+        if (v < 0) continue;
+        if (l.kind != LK_CONV || l.conv_slot < 0 || !convs[l.conv_slot].split) { set_error("set_tiles: launch %d is not a split-f16 convolution", i); return RTOD_E_ARG; }
+        const Layer& L = layers[l.layer];
+        const bool band = convs[l.conv_slot].band, hosts_pw = l.pw_guest >= 0 && pw_active();
+        bool ok;
+        if (band) ok = v >= BAND_VARIANT_BASE && v < BAND_VARIANT_BASE + BAND_MODES && conv_band_mode_valid(v - BAND_VARIANT_BASE, L.cin, L.hin, L.win);
+        else if (v >= PATCH_VARIANT_BASE) ok = v < PATCH_VARIANT_BASE + PATCH_MODES && !hosts_pw && l.out_layer != -2 && L.act <= 1 && L.hout == L.hin &&
+                                               conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, L.cin, L.cout);
+        else if (v >= RING_VARIANT_BASE) ok = v < RING_VARIANT_BASE + RING_MODES && !hosts_pw && L.act <= 1;
+        else ok = v < HV_COUNT && !(hosts_pw && conv_f16s3_variant_info(v).bn < L.cout);
+        if (!ok) { set_error("set_tiles: variant %d is not a valid tile of launch %d (layer %d)", v, i, l.layer); return RTOD_E_ARG; }
+    }
+    tuned[batch] = std::vector<int>(variants, variants + count);
+    return RTOD_OK;
+}
+
 int Plan::variant_for(const Launch& l, int batch) const {
     const bool band = convs[l.conv_slot].band;
     if (opt_force_f16s3_variant >= 0) {                      // >= BAND_VARIANT_BASE: tile of the band layers, below: of the others

@@ -122,6 +122,7 @@ struct Plan {
     int load_weights(const float* w, size_t n);
     int forward(const float* x, int batch, float* out, hipStream_t s, float* launch_ms, bool tune = false);
     int set_option(const char* name, int value);
+    int set_tiles(int batch, const int* variants, int count);   // install a tile table (validated per launch)
     void reset_planning();
     View view_of(int layer) const;            // resolves aliases; base == nullptr if not materialised
     int choose_variant(const Layer& L, int batch) const;

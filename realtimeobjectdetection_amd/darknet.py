@@ -35,14 +35,18 @@ from .cfg import parse_cfg, build_ir
 
 _OVERFLOW_MSG = ("Darknet (precision f16s3): an activation reached the split-f16 range limit (|x| >= 8188) and was saturated; "
                  "the results of that forward are not valid. Use precision='fp32' (exact MFMA kernels) for these weights.")
-_pending_overflow = {}      # output data_ptr -> weakref(model): util.write_results reads the model's overflow flag at its host sync
 
 
 def take_pending_overflow(prediction):
     """``(model, flag tensor)`` of the forward that produced ``prediction`` (or ``(None, None)``): util.write_results reads the
-    flag in the same host synchronisation as its detection counts instead of paying a second round trip."""
-    ref = _pending_overflow.pop(prediction.data_ptr(), None)
-    model = ref() if ref is not None else None
+    flag in the same host synchronisation as its detection counts instead of paying a second round trip.  The link is a tag on
+    the output tensor OBJECT itself — (weak reference to the model, its forward sequence number), set by Darknet.forward —
+    not the tensor's address: a freed-and-reused address can no longer attach a stale model to another tensor."""
+    tag = getattr(prediction, "_rtod_forward", None)
+    if tag is None:
+        return None, None
+    prediction._rtod_forward = None                            # consumed: a second write_results on the same tensor reads nothing
+    model = tag[0]()
     if model is None or model._ovf is None:
         return None, None
     return model, model._ovf
@@ -112,6 +116,7 @@ class Darknet(nn.Module):
         # precision "auto" the plan falls back to the exact-fp32 kernels and re-runs; "off": never read.
         self.overflow_check = "write_results"
         self._ovf = None
+        self._forward_seq = 0             # forwards whose range flag is still to be read (tag on the output tensor, see take_pending_overflow)
         self._tuned = set()
         self._cfg_text = _blocks_to_cfg_text(self.blocks)
         self._plan = None
@@ -316,6 +321,26 @@ class Darknet(nn.Module):
             self._plan_weights_version = version
         return self._info
 
+    # ------------------------------------------------------------------ tile tables (autotune results)
+    def get_tiles(self, batch: int) -> list:
+        """Tile variant per launch that autotune chose for this batch size (rtod_plan_get_tiles)."""
+        lib = _ffi.lib()
+        n = lib.rtod_plan_get_tiles(self._plan, int(batch), None, 0)
+        if n < 0:
+            _ffi.check(n)
+        arr = (C.c_int * n)()
+        got = lib.rtod_plan_get_tiles(self._plan, int(batch), arr, n)
+        if got < 0:
+            _ffi.check(got)
+        return list(arr)
+
+    def set_tiles(self, batch: int, variants) -> None:
+        """Install a tile table (e.g. saved by another process) for this batch size: forwards of that size then launch exactly
+        those kernels and measure nothing.  The plan must exist (prepare / a forward at a larger or equal batch size)."""
+        arr = (C.c_int * len(variants))(*[int(v) for v in variants])
+        _ffi.check(_ffi.lib().rtod_plan_set_tiles(self._plan, int(batch), arr, len(variants)))
+        self._tuned.add(int(batch))
+
     def plan_description(self) -> dict:
         lib = _ffi.lib()
         need = C.c_size_t()
@@ -384,9 +409,8 @@ class Darknet(nn.Module):
                     self.precision = "fp32"
                     return self.forward(x)
             else:
-                _pending_overflow[out.data_ptr()] = weakref.ref(self)
-                if len(_pending_overflow) > 64:
-                    _pending_overflow.pop(next(iter(_pending_overflow)))
+                self._forward_seq += 1
+                out._rtod_forward = (weakref.ref(self), self._forward_seq)
         return out
 
     def _update_running_stats(self, batch, stream):

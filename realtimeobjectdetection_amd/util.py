@@ -207,6 +207,24 @@ def nms_class_offset(prediction, num_class, conf_thres=0.25, iou_thres=0.45, max
     return out[:int(counts[0].item())].clone()
 
 
+def nms_class_offset_async(prediction, num_class, conf_thres=0.25, iou_thres=0.45, max_wh=7680.0, max_det=300, cap=None):
+    """nms_class_offset without the host synchronisation: device tensors ``(rows[cap,8], counts)``, ``counts[0]`` = valid rows
+    (buffers are reused by the next call of the same shape, like write_results_async's)."""
+    _need_cuda(prediction, "nms_class_offset")
+    if prediction.dim() != 3 or prediction.size(2) != 5 + int(num_class):
+        raise ValueError("nms_class_offset: expected [B,N,5+num_class], got %s" % (tuple(prediction.shape),))
+    x = prediction.contiguous()
+    B, n = x.size(0), x.size(1)
+    if cap is None:
+        cap = B * min(n, int(max_det))
+    ws, out, counts, nbytes = _nms_buffers(x.device, B, n, int(cap))
+    with torch.cuda.device(x.device):
+        _ffi.check(_ffi.lib().rtod_nms_class_offset(C.c_void_p(x.data_ptr()), B, n, int(num_class), float(conf_thres), float(iou_thres),
+                                                    float(max_wh), int(max_det), C.c_void_p(out.data_ptr()), int(cap),
+                                                    C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, _stream(x.device)))
+    return out, counts
+
+
 def write_results(prediction, num_class, confidence=0.6, nms_conf=0.4):
     """Reference-compatible: new ``[D,8]`` tensor, an empty ``[0,8]`` tensor when candidates existed
     but none had a non-zero class score (what the reference's concatenation yields), or int ``0``."""

@@ -45,8 +45,13 @@ def main():
                       "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
                       "hbm_bytes_per_launch": round(rd + wr)}
     json.dump({"note": "hbm_read = 2 * FETCH_SIZE(KiB) * 1024 (gfx950 correction), hbm_write = WRITE_SIZE(KiB) * 1024; "
-                       "separate --pmc passes of `bench.py --steps 3 --warmup 1` (includes the plan's autotune launches)",
+                       "separate --pmc passes of `bench.py --steps 3 --warmup 1 --inflight 1 --tiles <table of the timing run>`: the tile "
+                       "table is installed, not measured, so both passes launch the same kernels the same number of times "
+                       "(launches_fetch_pass == launches_write_pass) and no autotune launch is counted",
                "kernels": traffic}, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    tiles = os.path.join(src, "tiles.json")
+    if os.path.exists(tiles):
+        shutil.copy(tiles, os.path.join(out, f"{tag}_tiles.json"))
     for name in ("bench.log", "layers.json"):
         p = os.path.join(src, name)
         if os.path.exists(p):
@@ -56,7 +61,10 @@ def main():
             else:
                 shutil.copy(p, os.path.join(out, f"{tag}_{name}"))
     # traffic.json consumed by bench.py: keyed by the exact kernel names rocprofv3 reports
-    json.dump({k: v["hbm_bytes_per_launch"] for k, v in traffic.items()}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    json.dump({"source": f"profiles/{tag}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py with the timing run's tile "
+                         "table installed (2 * FETCH_SIZE + WRITE_SIZE per launch, equal launch counts in both passes); not measured in this run",
+               "kernels": {k: v["hbm_bytes_per_launch"] for k, v in traffic.items() if v["launches_fetch_pass"] == v["launches_write_pass"]}},
+              open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(out)))
 
 
