@@ -11,7 +11,7 @@ def load_schema():
     return json.load(open(GOLDEN))
 
 
-def validate_metrics(metrics, processing_order, num_classes, confidence, coord_max, schema=None):
+def validate_metrics(metrics, processing_order, num_classes, confidence, schema=None):
     """`metrics`: the parsed metrics.json; `processing_order`: image file names in the order the driver processed them.
     Raises AssertionError naming the first violated rule."""
     schema = schema or load_schema()
@@ -29,7 +29,7 @@ def validate_metrics(metrics, processing_order, num_classes, confidence, coord_m
             assert img == float(index_of[name]), "column 0 is the image's run-global index in processing order"
             assert cls == float(int(cls)) and 0 <= int(cls) < num_classes, "column 7 is an integral class index"
             assert confidence < obj <= 1.0 and 0.0 < score <= 1.0, "objectness above the confidence threshold, class score in (0, 1]"
-            assert x1 < x2 and y1 < y2 and -coord_max <= x1 and x2 <= 2 * coord_max and -coord_max <= y1 and y2 <= 2 * coord_max, "corner boxes in network-input pixels"
+            assert x1 < x2 and y1 < y2 and all(abs(c) < float("inf") for c in (x1, y1, x2, y2)), "finite corner boxes x1 < x2, y1 < y2 (network-input pixels)"
             key = (cls, -obj)
             assert prev is None or prev <= key, "rows of an image: class ascending, objectness descending inside a class (write_results order)"
             prev = key

@@ -105,7 +105,7 @@ def test_detector_driver_end_to_end(tmp_path):
     assert set(saved) == set(arrays) and saved == metrics
     # schema of the fixture the reference holds (det/metrics.json -> tests/golden/metrics_schema.json)
     from metrics_schema import validate_metrics
-    validate_metrics(saved, sorted(arrays), 80, 0.5, 416)
+    validate_metrics(saved, sorted(arrays), 80, 0.5)
     for name in arrays:
         assert os.path.exists(tmp_path / "det" / ("det_yolov3-tiny_" + name))
     m = Darknet(cfg_path, True).eval()
@@ -181,10 +181,10 @@ def test_reference_held_metrics_fixture_satisfies_the_schema_rules():
     s = load_schema()
     ref = s["reference_metrics"]
     assert s["n_images"] == 11 == len(ref) and s["n_rows"] == 32 and ref["scream.jpg"] == 0
-    validate_metrics(ref, s["processing_order"], 80, 0.6, 416, s)
+    validate_metrics(ref, s["processing_order"], 80, 0.6, s)
     bad = json.loads(json.dumps(ref)); bad["dog.jpg"][0][0] += 1.0
     with pytest.raises(AssertionError):
-        validate_metrics(bad, s["processing_order"], 80, 0.6, 416, s)
+        validate_metrics(bad, s["processing_order"], 80, 0.6, s)
     bad = json.loads(json.dumps(ref)); bad["scream.jpg"] = []
     with pytest.raises(AssertionError):
-        validate_metrics(bad, s["processing_order"], 80, 0.6, 416, s)
+        validate_metrics(bad, s["processing_order"], 80, 0.6, s)
