@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 struct Rec { unsigned hwid, xcc; unsigned long long t0, t1; };
@@ -23,10 +24,19 @@ __global__ __launch_bounds__(512) void census(Rec* out, int spin_ticks) {
 }
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 722, spin_us = argc > 2 ? atoi(argv[2]) : 20;
+    // optional CU mask (hipExtStreamCreateWithCUMask): argv[3] = 8 hex words, e.g. ffffffff,ffffffff,ffffffff,ffffffff,0,0,0,0
+    hipStream_t stream = 0;
+    if (argc > 3) {
+        unsigned mask[8] = {0}; int n = 0; char* tok = strtok(argv[3], ",");
+        while (tok && n < 8) { mask[n++] = (unsigned)strtoul(tok, nullptr, 16); tok = strtok(nullptr, ","); }
+        hipError_t e = hipExtStreamCreateWithCUMask(&stream, 8, mask);
+        printf("hipExtStreamCreateWithCUMask -> %s\n", hipGetErrorString(e));
+        if (e != hipSuccess) return 1;
+    }
     Rec* d; hipMalloc(&d, blocks * sizeof(Rec));
     hipFuncSetAttribute(reinterpret_cast<const void*>(census), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(census, dim3(blocks), dim3(512), 70 * 1024, 0, d, spin_us * 100);
+        hipLaunchKernelGGL(census, dim3(blocks), dim3(512), 70 * 1024, stream, d, spin_us * 100);
         hipDeviceSynchronize();
     }
     std::vector<Rec> h(blocks); hipMemcpy(h.data(), d, blocks * sizeof(Rec), hipMemcpyDeviceToHost);
@@ -42,6 +52,7 @@ int main(int argc, char** argv) {
                                               (h[b].t0 - tmin) / 100.0, (h[b].t1 - tmin) / 100.0);
     }
     printf("distinct CUs %zu\n", per_cu.size());
+    { int per_xcc[8] = {0}; for (auto& kv : per_cu) ++per_xcc[(kv.first >> 12) & 7]; printf("CUs per XCC:"); for (int i = 0; i < 8; ++i) printf(" %d", per_xcc[i]); printf("\n"); }
     printf("TG_ID histogram (all):"); for (int i = 0; i < 16; ++i) printf(" %d", tg_hist[i]); printf("\n");
     printf("TG_ID histogram (started within 2 us):"); for (int i = 0; i < 16; ++i) printf(" %d", first_round_tg[i]); printf("\n");
     int shown = 0;
