@@ -38,15 +38,12 @@
 namespace rtod {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 14 && N % 2 == 0, "vmcnt literal");
+    static_assert(N >= 0 && N <= 30 && N % 2 == 0, "vmcnt literal");
+#define RTOD_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(10) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(14)
+    RTOD_VMCNT_CASE(16) RTOD_VMCNT_CASE(18) RTOD_VMCNT_CASE(20) RTOD_VMCNT_CASE(22) RTOD_VMCNT_CASE(24) RTOD_VMCNT_CASE(26) RTOD_VMCNT_CASE(28) RTOD_VMCNT_CASE(30)
+#undef RTOD_VMCNT_CASE
 }
 template <typename T, int N> __device__ __forceinline__ void tie_regs(T (&r)[N]) {   // pins later uses below a preceding wait
     static_assert(N >= 1 && N <= 5, "tie_regs");
@@ -77,6 +74,15 @@ __device__ unsigned long long g_band_real[STAMP_BLOCKS * STAMP_WAVES];     // s_
 constexpr int TL_BLOCKS = 2048;
 __device__ unsigned long long g_band_tl[TL_BLOCKS * 4];
 #endif
+
+// Timing-only ablation of the main loop (never in a shipped library; outputs are garbage): -DRTOD_ABL=<bits>  1 no epilogue,
+// 2 no global loads (32: no band loads only, 64: no weight loads only), 4 no LDS writes, 8 fragments read once, 16 no barrier inside the loop,
+// 128 (with 2 / 64) keep wait_b's scheduling fences.  Used with -DRTOD_TIMELINE, whose
+// per-workgroup cycle counts separate cycles from the clock the chip holds.
+#ifndef RTOD_ABL
+#define RTOD_ABL 0
+#endif
+
 
 constexpr int BAND_MAX_W = 94;
 // Epilogue flavour.  0 (default): pixel-major accumulators, LDS-transposed stores (256-byte runs per pixel).  1: transposed
@@ -109,7 +115,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     constexpr int BAND_SLOTS = (BAND_MAX + RPP - 1) / RPP;
     static_assert(RPP % 16 == 0, "a pass that runs past a panel is predicated per 16-row wave slice; swizzle period 8");
     constexpr int B_LOADS = 2 * B_SLOTS, BAND_LOADS = 2 * BAND_SLOTS;
-    static_assert(B_LOADS + BAND_LOADS <= 14 && 2 * B_LOADS <= 14, "vmcnt literals");
+    static_assert(B_LOADS + BAND_LOADS <= 30 && 2 * B_LOADS <= 30, "vmcnt literals");
     constexpr int PANEL_B = BN * 64;
     constexpr int BSTAGE = 2 * PANEL_B;
 
@@ -198,6 +204,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     int ld_step = 0, ld_cc = 0, ld_tap = 0;                    // B chunk to be loaded next: local step, its chunk and tap
     auto gload_b = [&](BStage& S) {
+#if RTOD_ABL & (2 | 64)
+        return;
+#endif
         const bool live = ld_step < nsteps;
         const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * wchunk;
 #pragma unroll
@@ -210,6 +219,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         if (++ld_tap == 9) { ld_tap = 0; ++ld_cc; }
     };
     auto gload_band = [&](int cc) {
+#if RTOD_ABL & (2 | 32)
+        return;
+#endif
         const bool live = cc < n_cc;
         const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
 #pragma unroll
@@ -224,20 +236,40 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     // two steps after a band prefetch the band loads in between) may stay in flight.  The counted wait carries no
     // register operands (two alternative asm statements with tied operands make the compiler unify their outputs
     // with copies placed BEFORE the wait); one tying statement after the uniform branch pins the uses instead.
+    // (Round 3: a third register set — weights loaded three steps ahead — changed nothing, A/B on one box: what the weight
+    // loads cost, 14-21 % of these kernels in the timing-only builds of tools/run_abl.sh, is throughput, not latency.)
     int band_age = 0;                                          // steps since the last band prefetch was issued
     auto wait_b = [&](BStage& S) {
+#if RTOD_ABL & (2 | 64)
+#if RTOD_ABL & 128
+        tie_regs(S.bh); tie_regs(S.bl);                        // timing experiment: no loads, the scheduling fences kept
+        ++band_age;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        return;
+#endif
         if (band_age < 2) wait_vmcnt<B_LOADS + BAND_LOADS>(); else wait_vmcnt<B_LOADS>();
         tie_regs(S.bh); tie_regs(S.bl);
         ++band_age;
         __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_band = [&]() {                                   // everything issued so far except the two B sets
+#if RTOD_ABL & (2 | 32)
+        return;
+#endif
+#if RTOD_ABL & 64
+        wait_vmcnt<0>();
+#else
         wait_vmcnt<2 * B_LOADS>();
+#endif
         tie_regs(BRh); tie_regs(BRl);
         __builtin_amdgcn_sched_barrier(0);
     };
     const int wr_swz = (c16 ^ band_swz(row0)) << 4;            // RPP % 8 == 0: the same for every pass
     auto write_b = [&](const BStage& S, int buf) {
+#if RTOD_ABL & 4
+        return;
+#endif
         unsigned char* st = bst + buf * BSTAGE;
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
@@ -249,6 +281,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
     };
     auto write_band = [&]() {
+#if RTOD_ABL & 4
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < BAND_SLOTS; ++j) {
             const int o = (row0 + j * RPP) * 64 + wr_swz;
@@ -285,9 +320,17 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
     };
     // per 16-column group: two B fragments, then 3 TM products (lo*hi, hi*lo, hi*hi: small terms first)
+#if RTOD_ABL & 8
+    f16x8 bh[TN], bl[TN];
+    bool abl_have = false;
+#endif
     auto compute = [&](int buf) {
         const unsigned char* st = bst + buf * BSTAGE + b_lane;
+#if !(RTOD_ABL & 8)
         f16x8 bh[TN], bl[TN];
+#else
+        if (!abl_have)
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
@@ -334,6 +377,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
     auto step = [&](int buf, BStage& Snext) {
+#if RTOD_ABL & 8
+        if (!abl_have)
+#endif
         read_a(tap);
         wait_b(Snext);
         RTOD_STAMP(1)                                          // 1: A reads issued + wait for the staged B set
@@ -342,8 +388,13 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         __builtin_amdgcn_sched_barrier(0);
         RTOD_STAMP(2)                                          // 2: B LDS writes + next loads issued
         compute(buf);
+#if RTOD_ABL & 8
+        abl_have = true;
+#endif
         RTOD_STAMP(3)                                          // 3: B reads + MFMA issue
+#if !(RTOD_ABL & 16)
         __syncthreads();
+#endif
         RTOD_STAMP(4)                                          // 4: barrier
         if (++tap == 9) {
             tap = 0; ++cc;
@@ -352,7 +403,9 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                 write_band();
                 gload_band(cc + 1);
                 band_age = 0;
+#if !(RTOD_ABL & 16)
                 __syncthreads();
+#endif
                 RTOD_STAMP(5)                                  // 5: band replacement
             }
         }
@@ -371,12 +424,17 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #ifdef RTOD_DIAG
     if (a.dbg & 4) return;
 #endif
+#if RTOD_ABL
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));      // keep the accumulators (and the MFMAs) alive
+#endif
+#if !(RTOD_ABL & 1)
     if constexpr (BAND_TR) {
         int mrow[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int m = bm * BM + wm * WM + i * 16 + lr; mrow[i] = m < M ? m : -1; }
         conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, mrow, bn * BN + wn * WN, tid, lh, kg);
     } else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+#endif
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {
