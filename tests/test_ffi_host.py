@@ -314,3 +314,45 @@ def test_launch_kernel_names_have_the_format_rocprofv3_prints():
             seen.add(fam[0])
         lib.rtod_plan_destroy(h)
     assert {"conv_band_f16s3_kernel", "conv_patch_wres_f16s3_kernel", "conv_patch_f16s3_kernel", "conv_ring_f16s3_kernel", "conv_stem2_f16s3_kernel"} <= seen
+
+
+def test_tile_table_is_validated_per_launch():
+    """rtod_plan_set_tiles (bench.py --tiles: profiled passes replay the timing run's kernels) refuses tables that do not fit the
+    plan — wrong length, a band tile on a non-band layer, a generic tile on a band layer, a split-K mode on a layer that does not
+    split K — and get_tiles returns what set_tiles installed (host-only: nothing is launched)."""
+    lib = _ffi.lib()
+    rc, h = _plan(cfgs.yolov3_cfg(), 608)
+    assert rc == 0 and lib.rtod_plan_set_precision(h, 1) == 0, _ffi.last_error()
+    info = _ffi.PlanInfo()
+    assert lib.rtod_plan_get_info(h, C.byref(info)) == 0
+    n = info.n_launches
+    assert lib.rtod_plan_get_tiles(h, 8, None, 0) == -4 and "autotune" in _ffi.last_error()      # RTOD_E_STATE: nothing tuned yet
+    infos = []
+    for i in range(n):
+        li = _ffi.LaunchInfo()
+        assert lib.rtod_plan_get_launch(h, i, C.byref(li)) == 0
+        infos.append((li.kind, li.variant, li.ksize, li.stride, li.hout, li.flops_per_frame))
+    band = [i for i, (k, v, *_r) in enumerate(infos) if k == 0 and 150 <= v < 170]
+    ring_or_generic = [i for i, (k, v, ks, st, ho, fl) in enumerate(infos) if k == 0 and fl > 0 and ks == 1 and 100 <= v < 150 or (k == 0 and 170 <= v < 190)]
+    assert band and ring_or_generic
+    table = [-1] * n
+    arr = lambda t: (C.c_int * len(t))(*t)
+    assert lib.rtod_plan_set_tiles(h, 8, arr(table[:-1]), n - 1) == -1                           # wrong length
+    t = list(table); t[band[0]] = 50 + 3
+    t[ring_or_generic[0]] = 70 + 2
+    assert lib.rtod_plan_set_tiles(h, 8, arr(t), n) == 0, _ffi.last_error()
+    got = (C.c_int * n)()
+    assert lib.rtod_plan_get_tiles(h, 8, got, n) == n and list(got) == t
+    li = _ffi.LaunchInfo()
+    assert lib.rtod_plan_get_launch(h, band[0], C.byref(li)) == 0 and li.variant == 153
+    bad = list(table); bad[ring_or_generic[0]] = 50                                              # band tile on a 1x1 layer
+    assert lib.rtod_plan_set_tiles(h, 8, arr(bad), n) == -1 and "not a valid tile" in _ffi.last_error()
+    bad = list(table); bad[band[0]] = 6                                                          # generic tile on a band layer
+    assert lib.rtod_plan_set_tiles(h, 8, arr(bad), n) == -1
+    k2 = [i for i in band if infos[i][4] == 19]
+    bad = list(table); bad[k2[0]] = 50                                                           # 19x19: split-K layer, mode 0 is not
+    assert lib.rtod_plan_set_tiles(h, 8, arr(bad), n) == -1
+    bad = list(table); bad[band[0]] = 57                                                         # split-K mode on a 76x76 layer
+    assert lib.rtod_plan_set_tiles(h, 8, arr(bad), n) == -1
+    assert lib.rtod_plan_set_tiles(h, 9, arr(t), n) == -1                                        # batch beyond max_batch
+    lib.rtod_plan_destroy(h)

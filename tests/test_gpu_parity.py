@@ -928,3 +928,41 @@ def test_make_graphed_replays_forward_and_write_results(tmp_path_factory):
         torch.cuda.synchronize()
         assert torch.equal(y, wy) and torch.equal(c, wc)
         assert torch.equal(r[:int(c[0])], wr[:int(wc[0])])
+
+
+def test_installed_tile_table_replays_the_autotuned_launches(tmp_path_factory):
+    """bench.py --tiles / rtod_plan_set_tiles: the table one plan's autotune left, installed in a second plan, gives the same
+    per-launch kernels and the same bits without measuring anything (what makes the rocprofv3 --pmc passes replay the timing
+    run: equal launch counts in the FETCH_SIZE and WRITE_SIZE passes)."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    res, B = 416, 2
+    cfg_text = NETS["yolov3"]()
+    d = tmp_path_factory.mktemp("tiles")
+    cfg_path = cfgs.write_cfg(str(d / "yolov3.cfg"), cfg_text)
+    w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
+    x = torch.from_numpy(synth.synth_frames(B, res)).cuda()
+
+    def model():
+        m = Darknet(cfg_path, True).eval()
+        m.net_info["height"] = res
+        m.precision = "f16s3"
+        m.load_weight_stream(w)
+        return m
+    a = model()
+    with torch.no_grad():
+        ya = a(x)                                              # autotunes batch 2
+    table = a.get_tiles(B)
+    assert len(table) == a._info.n_launches and any(v >= 0 for v in table)
+    b = model()
+    b.autotune = False
+    b.prepare(B, x.device)
+    b.set_tiles(B, table)
+    with torch.no_grad():
+        yb = b(x)
+    torch.cuda.synchronize()
+    assert b.get_tiles(B) == table
+    assert [li.variant for li in a.launch_infos()] == [li.variant for li in b.launch_infos()]
+    assert torch.equal(ya, yb)
+    bad = list(table); bad[0] = 999
+    with pytest.raises(Exception):
+        b.set_tiles(B, bad)
