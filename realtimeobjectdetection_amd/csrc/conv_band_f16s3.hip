@@ -92,7 +92,8 @@ constexpr int BAND_MAX_W = 94;
 #define RTOD_BAND_TR 0
 #endif
 constexpr bool BAND_TR = RTOD_BAND_TR != 0;
-constexpr int BAND_EPI_BYTES = BAND_TR ? 0 : 65536;      // LDS-transposed epilogue: the launch allocates at least the transpose tile
+// LDS-transposed epilogue: the launch allocates at least the transpose tile — the whole BM x BN fp32 tile, capped at 64 KiB (more rows go in passes)
+__host__ __device__ constexpr int band_epi_bytes(int bm, int bn) { return BAND_TR ? 0 : (bm * bn * 4 < 65536 ? bm * bn * 4 : 65536); }
 __host__ __device__ constexpr int band_rows(int bm, int w) { return (bm + 2 * w + 2 + 15) / 16 * 16; }   // zero row follows
 
 // BM x BN workgroup tile, NWM x NWN waves of (BM/NWM) x (BN/NWN); MINW = waves/SIMD the register budget must allow.
@@ -433,7 +434,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int m = bm * BM + wm * WM + i * 16 + lr; mrow[i] = m < M ? m : -1; }
         conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, mrow, bn * BN + wn * WN, tid, lh, kg);
-    } else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, BAND_EPI_BYTES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+    } else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, band_epi_bytes(BM, BN), KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
 #endif
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
@@ -467,7 +468,7 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
     ConvArgs ax = a;
     ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
     const int main_bytes = KG * (4 * BN * 64 + 2 * (band_rows(BM, a.Wi) + 1) * 64);
-    const int lds = main_bytes > BAND_EPI_BYTES ? main_bytes : BAND_EPI_BYTES;
+    const int lds = main_bytes > band_epi_bytes(BM, BN) ? main_bytes : band_epi_bytes(BM, BN);
     auto k_res = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, KG>;
     auto k_plain = conv_band_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, KG>;
     static std::atomic<unsigned long long> attr_done{0};       // per instantiation, one bit per device; > 64 KiB of dynamic LDS needs the opt-in
@@ -475,7 +476,7 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_band_f16s3 hipGetDevice");
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {       // idempotent: a second thread may repeat the calls
         const int cap = KG * (4 * BN * 64 + 2 * (band_rows(BM, BAND_MAX_W) + 1) * 64);
-        const int mx = cap > BAND_EPI_BYTES ? cap : BAND_EPI_BYTES;
+        const int mx = cap > band_epi_bytes(BM, BN) ? cap : band_epi_bytes(BM, BN);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return hip_fail(hipGetLastError(), "conv_band_f16s3 LDS attribute");
