@@ -966,3 +966,61 @@ def test_installed_tile_table_replays_the_autotuned_launches(tmp_path_factory):
     bad = list(table); bad[0] = 999
     with pytest.raises(Exception):
         b.set_tiles(B, bad)
+
+
+def test_f16s3_wide_dynamic_range_vs_oracle(tmp_path_factory):
+    """No trained weights exist offline, and the synthetic ones keep every tensor O(1).  Trained networks do
+    not: this drives the split-f16 format over six decades inside one YOLOv3 — the output of the 1x1 conv of every residual block scaled by
+    512 or 1/512 (alternating, exactly: BatchNorm gamma / beta) and the 3x3 conv that alone consumes it by the inverse, so tensors of magnitude ~4e3 (just under
+    the format's 8188 limit) and ~1e-2 (low parts in the f16 subnormal range) sit next to ordinary ones — and checks every
+    materialised layer against the oracle at the usual 2e-5 of its own absmax, the output at 1e-4, and that the range flag
+    stays down."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    res, B = 416, 1
+    cfg_text = NETS["yolov3"]()
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    convs = {L.index: L for L in ref.ir.layers if L.type == "convolutional"}
+    pairs = [i for i in sorted(convs) if convs[i].size == 1 and (i + 1) in convs and convs[i + 1].size == 3 and (i + 2) < len(ref.ir.layers)
+             and ref.ir.layers[i + 2].type == "shortcut"]
+    assert len(pairs) == 23
+    # exact rescaling by powers of two: BatchNorm gamma and beta of the 1x1 conv times s (its output is then exactly s times the
+    # original, leaky-ReLU included), the consuming 3x3 conv's weights times 1/s — the network FUNCTION is unchanged bit for bit
+    # in fp32, only the tensors between the two layers move to another magnitude
+    sl = synth.conv_weight_slices(ref.ir)
+    w = w.copy()
+    for n, i in enumerate(pairs):
+        sc = np.float32(512.0 if n % 2 == 0 else 1.0 / 512.0)
+        c = convs[i].cout
+        a = sl[i][0] - 4 * c                               # block: beta, gamma, running_mean, running_var, weights
+        w[a:a + 2 * c] *= sc                               # beta, gamma
+        a1, b1 = sl[i + 1]
+        w[a1:b1] *= np.float32(1.0) / sc
+    ref.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=11))
+    with torch.no_grad():
+        want, outs = ref.forward(x, keep_layers=True)
+    big = max(float(outs[i].abs().max()) for i in pairs[0::2])
+    small = max(float(outs[i].abs().max()) for i in pairs[1::2])
+    assert 1000.0 < big < 8188.0 and small < 0.1, (big, small)
+    d = tmp_path_factory.mktemp("range")
+    m = Darknet(cfgs.write_cfg(str(d / "yolov3.cfg"), cfg_text), True).eval()
+    m.net_info["height"] = res
+    m.precision = "f16s3"
+    m.keep_all_layers = True
+    m.load_weight_stream(w)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert not m.overflowed()
+    worst = 0.0
+    for D in m.plan_description()["layers"]:
+        i = D["index"]
+        if D["type"] == "yolo" or (D["type"] == "convolutional" and D["fused_into"] >= 0):
+            continue
+        got = m.read_layer(i, B).cpu().numpy()
+        wv = outs[i].numpy()
+        scale = float(np.abs(wv).max())                    # the layer's OWN absmax (no floor of 1: the small tensors are ~1e-2)
+        err = float(np.abs(got - wv).max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-5, f"layer {i} ({D['type']}, absmax {scale:.3g}): max err/absmax {err:.3e}"
+    assert rel_err(y.cpu().numpy(), want.numpy()).max() <= TOL
