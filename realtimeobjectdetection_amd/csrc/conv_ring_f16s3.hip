@@ -76,6 +76,12 @@ __device__ __forceinline__ void dma_pair(const __amdgpu_buffer_rsrc_t rsrc_hi, c
 // LDS: [STAGES][A hi BM x 64 B | A lo | B hi BN x 64 B | B lo].  The epilogue's transpose tile is the ring slot the last
 // K step has just been computed from: the loader runs STAGES-1 steps ahead, so exactly that slot is free until the
 // next tile's first barrier.
+// Diagnostic build only (make timeline): start / end wall clock of every workgroup of a launch, as in conv_band_f16s3.hip.
+#ifdef RTOD_TIMELINE
+constexpr int RING_TL_BLOCKS = 1024;
+__device__ unsigned long long g_ring_tl[RING_TL_BLOCKS * 2];
+#endif
+
 template <int BM, int BN, int NWM, int NWN, int STAGES, int MINW, int EPI>
 __global__ __launch_bounds__(NWM * NWN * 64, MINW)
 void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
@@ -97,6 +103,9 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     constexpr bool TRANSPOSED = EPI != EPI_DECODE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef RTOD_TIMELINE
+    const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -269,6 +278,10 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
     }
     ring_wait_vmcnt<0>();                                        // trailing (out-of-range) pieces: nothing may be in flight at exit
+#ifdef RTOD_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < RING_TL_BLOCKS) { g_ring_tl[blockIdx.x * 2] = tl_start_; g_ring_tl[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
@@ -320,6 +333,23 @@ static int launch_ring(const ConvArgs& a, hipStream_t s) {
     if (a.dec.enabled) hipLaunchKernelGGL(k_dec, dim3(grid), dim3(NT), lds, s, a, gm, gn);
     else if (a.res) hipLaunchKernelGGL(k_res, dim3(grid), dim3(NT), lds, s, a, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(grid), dim3(NT), lds, s, a, gm, gn);
+#ifdef RTOD_TIMELINE
+    {
+        static int printed = 0;
+        const int nb = grid < RING_TL_BLOCKS ? grid : RING_TL_BLOCKS;
+        if (printed < 80 && hipDeviceSynchronize() == hipSuccess) {
+            static unsigned long long h[RING_TL_BLOCKS * 2];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ring_tl), sizeof(unsigned long long) * 2 * nb) == hipSuccess) {
+                unsigned long long t0 = ~0ull, t1 = 0; double d = 0, smax = 0, emin = 1e9;
+                for (int b = 0; b < nb; ++b) { if (h[b * 2] < t0) t0 = h[b * 2]; if (h[b * 2 + 1] > t1) t1 = h[b * 2 + 1]; }
+                for (int b = 0; b < nb; ++b) { d += (h[b * 2 + 1] - h[b * 2]) / 100.0; const double st = (h[b * 2] - t0) / 100.0, en = (h[b * 2 + 1] - t0) / 100.0; if (st > smax) smax = st; if (en < emin) emin = en; }
+                fprintf(stderr, "[timeline] ring<%d,%d,%dx%d,s%d> k=%d Ho=%d Cin=%d Cout=%d tiles=%d wgs=%d | span %.1f us | wg mean %.1f us | last start %.1f | first end %.1f\n",
+                        BM, BN, NWM, NWN, STAGES, a.kh, a.Ho, a.Cin, a.Cout, tiles, grid, (t1 - t0) / 100.0, d / nb, smax, emin);
+                ++printed;
+            }
+        }
+    }
+#endif
     return hip_fail(hipGetLastError(), "conv_ring_f16s3 launch");
 }
 
