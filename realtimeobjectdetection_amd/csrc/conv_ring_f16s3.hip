@@ -37,10 +37,6 @@
 #include <cstdio>
 #include <cstdlib>
 
-#ifndef RTOD_RING_ORDER
-#define RTOD_RING_ORDER 1
-#endif
-
 namespace rtod {
 
 // this wave's vector-memory operations except the N youngest have completed (loads, stores and LDS-DMA count together,
@@ -231,6 +227,10 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         for (int kc = 0; kc < nk; ++kc) {
             ring_wait_vmcnt<(STAGES - 2) * LPW>();               // this wave's pieces of the current step have landed (the younger STAGES-2 stages may stay in flight)
             __builtin_amdgcn_s_barrier();                        // ... and everybody's; the previous step's slot is free
+            {
+                const int prev = slot == 0 ? STAGES - 1 : slot - 1;
+                loader_issue(prev);                              // the stage STAGES-1 steps ahead (possibly of the next tile)
+            }
             const unsigned char* st = smem + slot * STAGE;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -243,16 +243,6 @@ void conv_ring_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                 bh[j] = *reinterpret_cast<const f16x8*>(st + b_row + j * 16 * 64);
                 bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + b_row + j * 16 * 64);
             }
-#if RTOD_RING_ORDER
-            __builtin_amdgcn_sched_barrier(0);                   // fragment reads issued first: they land while the DMA pieces issue
-#endif
-            {
-                const int prev = slot == 0 ? STAGES - 1 : slot - 1;
-                loader_issue(prev);                              // the stage STAGES-1 steps ahead (possibly of the next tile)
-            }
-#if RTOD_RING_ORDER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
