@@ -500,7 +500,8 @@ def run_rank(args):
             try:
                 tr = json.load(open(tr_path))
                 roof["traffic"] = tr.get("kernels", tr).get(roof["kernel"])
-                roof["traffic_source"] = tr.get("source", "profiles/traffic.json (rocprofv3 --pmc passes, not this run)")
+                if roof["traffic"] is not None:
+                    roof["traffic_source"] = tr.get("source", "profiles/traffic.json (rocprofv3 --pmc passes, not this run)")
             except Exception:
                 pass
         if args.layers_out:
