@@ -59,7 +59,7 @@ __device__ __forceinline__ int band_swz(int row) { return (row >> 1) & 3; }
 // Diagnostic build only (make stamps -> librtod_stamps.so, -DRTOD_STAMPS): per-wave s_memtime attribution of the main
 // loop's phases, written to a device table the launcher prints.  The product library compiles none of it.
 #ifdef RTOD_STAMPS
-constexpr int STAMP_SLOTS = 8, STAMP_BLOCKS = 128, STAMP_WAVES = 16;
+constexpr int STAMP_SLOTS = 10, STAMP_BLOCKS = 128, STAMP_WAVES = 16;    // 8 / 9: slot 1 of the steps 2 / 0-1 steps after a band prefetch was issued
 __device__ unsigned long long g_band_stamps[STAMP_BLOCKS * STAMP_WAVES * (STAMP_SLOTS + 1)];
 __device__ unsigned long long g_band_real[STAMP_BLOCKS * STAMP_WAVES];     // s_memrealtime ticks (100 MHz) over the same span: the clock the chip held
 #define RTOD_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ts_[i] += tn_ - tprev_; tprev_ = tn_; }
@@ -354,7 +354,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     };
 
 #ifdef RTOD_STAMPS
-    unsigned long long ts_[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts_[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart_ = tprev_;
     const unsigned long long rstart_ = __builtin_amdgcn_s_memrealtime();
@@ -381,8 +381,15 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #if RTOD_ABL & 8
         if (!abl_have)
 #endif
+#ifdef RTOD_STAMPS
+        const int age_ = band_age;
+#endif
         read_a(tap);
         wait_b(Snext);
+#ifdef RTOD_STAMPS
+        // vmcnt retires in order: the B set waited for 2 steps after a band prefetch was issued BEHIND those band loads (slot 8)
+        if (age_ == 2) RTOD_STAMP(8) else if (age_ < 2) RTOD_STAMP(9) else
+#endif
         RTOD_STAMP(1)                                          // 1: A reads issued + wait for the staged B set
         write_b(Snext, buf ^ 1);
         gload_b(Snext);
