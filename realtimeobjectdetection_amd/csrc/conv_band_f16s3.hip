@@ -91,6 +91,9 @@ constexpr int BAND_MAX_W = 94;
 #ifndef RTOD_BAND_TR
 #define RTOD_BAND_TR 0
 #endif
+#ifndef RTOD_BFRAG_AHEAD
+#define RTOD_BFRAG_AHEAD 1
+#endif
 constexpr bool BAND_TR = RTOD_BAND_TR != 0;
 // LDS-transposed epilogue: the launch allocates at least the transpose tile — the whole BM x BN fp32 tile, capped at 64 KiB (more rows go in passes)
 __host__ __device__ constexpr int band_epi_bytes(int bm, int bn) { return BAND_TR ? 0 : (bm * bn * 4 < 65536 ? bm * bn * 4 : 65536); }
@@ -332,13 +335,25 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #else
         if (!abl_have)
 #endif
+#if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
+        // B fragments two column groups ahead of their products: a read is covered by the 3 TM MFMAs of the group before it
+        // (left to itself the scheduler reads each pair just in time — 8 registers of fragments, a wait in front of every MFMA pair)
+        auto read_bj = [&](int j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
+            bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
+        };
+        read_bj(0);
+        if constexpr (TN > 1) read_bj(1);
+        __builtin_amdgcn_sched_group_barrier(0x100, TN > 1 ? 4 : 2, 0);
+#else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
             bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
         }
+#endif
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if constexpr (BAND_TR) {
@@ -351,6 +366,11 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             }
+#if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
+            if (j + 2 < TN) { read_bj(j + 2); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#endif
+        }
     };
 
 #ifdef RTOD_STAMPS

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-launch timing table of one YOLOv3 forward (hipEvent pair around every launch), optionally with plan options:
     python tools/exp_layers.py out.json [res] [batch] [opt=val ...]
-With RTOD_LIB=librtod_diag.so and RTOD_DBG_ZERO=<bits> this is the load / epilogue ablation (results are then garbage)."""
+With RTOD_LIB=librtod_diag.so and RTOD_DBG_ZERO=<bits> this is the load / epilogue ablation (results are then garbage).
+RTOD_TILES=<file saved by bench.py --tiles> installs that tile table instead of autotuning."""
 import json, os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -20,6 +21,10 @@ m.autotune = opts.pop("autotune", 1) != 0
 m.options.update(opts)
 m.load_weight_stream(synth.synth_weights(ir))
 x = torch.from_numpy(synth.synth_frames(B, res)).cuda()
+if os.environ.get("RTOD_TILES"):                      # a tile table saved by bench.py --tiles: no autotune, the same kernels in every process
+    table = json.load(open(os.environ["RTOD_TILES"])).get("f16s3_%d_b%d" % (res, B))
+    if table is not None:
+        m.prepare(B); m.set_tiles(B, table)
 with torch.no_grad():
     m(x); m(x)
     tot = None
