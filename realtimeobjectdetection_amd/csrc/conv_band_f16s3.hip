@@ -94,6 +94,9 @@ constexpr int BAND_MAX_W = 94;
 #ifndef RTOD_BFRAG_AHEAD
 #define RTOD_BFRAG_AHEAD 1
 #endif
+#ifndef RTOD_BFRAG_LA
+#define RTOD_BFRAG_LA(minw, tn) 2
+#endif
 constexpr bool BAND_TR = RTOD_BAND_TR != 0;
 // LDS-transposed epilogue: the launch allocates at least the transpose tile — the whole BM x BN fp32 tile, capped at 64 KiB (more rows go in passes)
 __host__ __device__ constexpr int band_epi_bytes(int bm, int bn) { return BAND_TR ? 0 : (bm * bn * 4 < 65536 ? bm * bn * 4 : 65536); }
@@ -336,15 +339,19 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         if (!abl_have)
 #endif
 #if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
-        // B fragments two column groups ahead of their products: a read is covered by the 3 TM MFMAs of the group before it
-        // (left to itself the scheduler reads each pair just in time — 8 registers of fragments, a wait in front of every MFMA pair)
+        // B fragments LA = 2 column groups ahead of their products: a read is covered by the 3 TM MFMAs of the group before it
+        // (left to itself the scheduler reads each pair just in time — 8 registers of fragments, a wait in front of every MFMA
+        // pair).  A/B on one box, 76x76 / 38x38 layers: -3.3 % / -2.0 %; LA = 1: as before; LA = 3 or all four groups up front
+        // on the 12-wave tile (registers allow it there): +2-3 % at 38x38; the first two groups at the top of the step, ahead of
+        // the weight wait: no change; s_setprio 1 around the MFMA block: +2-7 %  (profiles/experiments/r03_bfrag_ahead.log).
+        constexpr int LA = RTOD_BFRAG_LA(MINW, TN) < TN ? RTOD_BFRAG_LA(MINW, TN) : TN;     // column groups read ahead
         auto read_bj = [&](int j) {
             bh[j] = *reinterpret_cast<const f16x8*>(st + j * 16 * 64);
             bl[j] = *reinterpret_cast<const f16x8*>(st + PANEL_B + j * 16 * 64);
         };
-        read_bj(0);
-        if constexpr (TN > 1) read_bj(1);
-        __builtin_amdgcn_sched_group_barrier(0x100, TN > 1 ? 4 : 2, 0);
+#pragma unroll
+        for (int j = 0; j < LA; ++j) read_bj(j);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * LA, 0);
 #else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -368,7 +375,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
             }
 #if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
-            if (j + 2 < TN) { read_bj(j + 2); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+            if (j + LA < TN) { read_bj(j + LA); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
 #endif
         }
     };
