@@ -595,7 +595,7 @@ bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
 //   X(mode, BM, BN, waves along M, waves along N, MINW, K groups, name suffix)
 #define RTOD_BAND_TILES(X) \
-    X(0, 128, 128, 4, 2, 4, 1, "") X(1, 128, 64, 4, 2, 4, 1, "") X(2, 192, 128, 4, 2, 3, 1, "") X(3, 192, 128, 6, 2, 3, 1, "") \
+    X(0, 128, 128, 4, 2, 4, 1, "") X(1, 128, 64, 4, 2, 4, 1, "") X(2, 192, 128, 4, 2, 2, 1, "") X(3, 192, 128, 6, 2, 3, 1, "") \
     X(4, 96, 128, 2, 4, 4, 1, "") X(5, 128, 128, 2, 2, 2, 1, "") X(6, 64, 128, 2, 4, 4, 1, "") \
     X(7, 96, 128, 2, 4, 4, 2, ",k2") X(8, 128, 128, 4, 2, 4, 2, ",k2") X(9, 64, 128, 2, 4, 4, 2, ",k2") X(10, 128, 64, 4, 2, 4, 2, ",k2")
 

@@ -113,8 +113,8 @@ __device__ __forceinline__ void conv_f16s3_epilogue_regs(const ConvArgs& a, f32x
                 const int m = mrow[i];
                 const bool ok = m >= 0 && cok;
                 const _Float16* q = rh + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + cc;
-                rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};     // (unconditional loads + select, as in the
+                rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};   //  LDS epilogue below: +6 % on the patch kernel, measured)
             }
         }
         f32x4 iv0 = *reinterpret_cast<const f32x4*>(a.inv_scale + cc), iv1 = *reinterpret_cast<const f32x4*>(a.inv_scale + cc + 4);
@@ -209,8 +209,23 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
     const float escale = (EPI == EPI_DECODE) ? 1.0f : SPLIT_SCALE;   // (acc*inv + bias)*8 == acc*(8 inv) + 8 bias exactly
     constexpr int GPR_ = BN / 8;                                          // 8-channel (16-byte) groups per row
     constexpr int NG = (RG * GPR_ + NT - 1) / NT;                         // groups per thread and pass
+    // bias / scale of the wave's TN column groups: all loads first and ahead of the residual loads (vmcnt retires in order: the
+    // transpose must not wait for those), from a clamped index and selected afterwards — the conditional form
+    // `n < Cout ? bias[n] : 0` cost a branch and a full memory wait per value, 2 TN of them in a row
+    // (loaded at the top of every pass: held across the passes of a multi-pass epilogue they cost the generic tiles 10-60 registers)
 #pragma unroll 1
     for (int rg = 0; rg < BM; rg += RG) {
+        float bias_j[TN], inv_j[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if constexpr (PRE) { bias_j[j] = pre_bias[j]; inv_j[j] = pre_inv[j]; }
+            else {
+                const int n = bn * BN + wn * WN + j * MT + lr;
+                const int nc = n < a.Cout ? n : 0;
+                const float b = a.bias[nc], iv = a.inv_scale[nc];
+                bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
+            }
+        }
         // residual operands of this pass: issued ahead of the transpose so that their latency (HBM / L2, ~2 us when
         // waited for inside the store loop: in-kernel stamps showed the epilogue at 15 % of a 76x76 tile) overlaps the
         // accumulator -> LDS phase and the barrier
@@ -223,9 +238,12 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
                 const int r = g / GPR_, c8 = (g - r * GPR_) * 8;
                 const int m = bm * BM + rg + r;
                 const bool ok = g < RG * GPR_ && m < M && bn * BN + c8 < a.Cout;
+                // unconditional loads from a clamped address, selected afterwards: written as `ok ? *q : 0` each load became a
+                // branch with its own s_waitcnt vmcnt(0) — NG pairs of memory latencies in a row at the head of every epilogue
                 const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
-                rq_h[i] = ok ? *reinterpret_cast<const f16x8*>(q) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                rq_l[i] = ok ? *reinterpret_cast<const f16x8*>(q + a.res_ldc) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                const f16x8 th = *reinterpret_cast<const f16x8*>(q), tl = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
+                rq_h[i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
         if constexpr (KG == 2) {
@@ -240,15 +258,12 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
             }
             __syncthreads();
         }
-        if (kg == 0 && wm * WM >= rg && wm * WM < rg + RG) {
+        if ((KG == 1 || kg == 0) && (RG == BM || (wm * WM >= rg && wm * WM < rg + RG))) {     // single pass, one K group: no branch
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nl = wn * WN + j * MT + lr;
-                const int n = bn * BN + nl;
-                float bias, inv;
-                if constexpr (PRE) { bias = pre_bias[j] * escale; inv = pre_inv[j] * escale; }
-                else { bias = (n < a.Cout ? a.bias[n] : 0.f) * escale; inv = (n < a.Cout ? a.inv_scale[n] : 0.f) * escale; }
-                auto col = [&](auto silu) {
+                const float bias = bias_j[j] * escale, inv = inv_j[j] * escale;
+                auto col = [&](auto act) {                                   // 0 linear, 1 leaky, 2 SiLU
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -257,12 +272,15 @@ __device__ __forceinline__ void conv_f16s3_epilogue(const ConvArgs& a, f32x4 (&a
                             float s = acc[i][j][e];
                             if constexpr (KG == 2) s += T[rl * TS + nl];
                             float v = s * inv + bias;
-                            if constexpr (decltype(silu)::value) v = silu_scaled(v, 1.0f / escale);
-                            else { if (a.leaky) v = v > 0.f ? v : v * 0.1f; }
+                            if constexpr (decltype(act)::value == 2) v = silu_scaled(v, 1.0f / escale);
+                            else if constexpr (decltype(act)::value == 1) v = __builtin_fmaxf(v, v * 0.1f);   // == v > 0 ? v : 0.1 v, bit for bit (signed zeros, infinities, NaN)
                             T[rl * TS + nl] = v;
                         }
                 };
-                if (a.leaky == 2) col(std::true_type{}); else col(std::false_type{});      // uniform
+                // uniform three-way branch around the loop: a per-value `if (a.leaky)` was a compare, a mask OR and a select per element
+                if (a.leaky == 2) col(std::integral_constant<int, 2>{});
+                else if (a.leaky) col(std::integral_constant<int, 1>{});
+                else col(std::integral_constant<int, 0>{});
             }
         }
         __syncthreads();

@@ -293,7 +293,7 @@ void conv_igemm_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #define RTOD_IGEMM_TILES(X) \
     X(HV_128x128, 128, 128, 2, 2, 2) X(HV_128x64, 128, 64, 2, 2, 3) X(HV_64x64, 64, 64, 2, 2, 4) X(HV_64x128, 64, 128, 2, 2, 3) \
     X(HV_256x128, 256, 128, 4, 2, 2) X(HV_128x256, 128, 256, 2, 4, 2) X(HV_128x128_8W, 128, 128, 4, 2, 4) X(HV_128x64_8W, 128, 64, 4, 2, 4) \
-    X(HV_256x128_16W, 256, 128, 8, 2, 4) X(HV_192x128_8W, 192, 128, 4, 2, 3) X(HV_96x128_8W, 96, 128, 2, 4, 4) X(HV_192x128_12W, 192, 128, 6, 2, 3)
+    X(HV_256x128_16W, 256, 128, 8, 2, 4) X(HV_192x128_8W, 192, 128, 4, 2, 2) X(HV_96x128_8W, 96, 128, 2, 4, 4) X(HV_192x128_12W, 192, 128, 6, 2, 3)
 
 #define RTOD_X_INFO(id, bm, bn, nwm, nwn, minw) {bm, bn, "conv_igemm_f16s3<" #bm "x" #bn "," #nwm "x" #nwn ">"},
 static const ConvVariantInfo kHVariants[HV_COUNT] = { RTOD_IGEMM_TILES(RTOD_X_INFO) };
