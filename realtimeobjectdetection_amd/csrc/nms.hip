@@ -157,15 +157,18 @@ void nms_filter_kernel(const float* __restrict__ pred, int B, int n, int num_cla
             int rr[4]; float v0[4], v1[4], ob[4]; f32x4 bx[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                rr[q] = -1;
-                if (mask) {
-                    rr[q] = row0 + __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const float* p = img + (int64_t)rr[q] * attrs;
-                    v0[q] = lane < num_class ? p[5 + lane] : -INFINITY;
-                    v1[q] = lane + 64 < num_class ? p[5 + lane + 64] : -INFINITY;
-                    if (lane == 0) { bx[q] = f32x4{p[0], p[1], p[2], p[3]}; ob[q] = p[4]; }
-                }
+                // branch-free: a missing row re-reads the wave's first row (in range: the loop runs only with a candidate), a
+                // missing class lane re-reads class 0, every lane reads the box — as `cond ? p[i] : x` each load was a branch with
+                // its own memory wait and the four rows' latencies ran one after the other
+                const bool have = mask != 0;
+                const int r = have ? row0 + __ffsll((long long)mask) - 1 : row0;
+                rr[q] = have ? r : -1;
+                mask &= mask - 1;                                // 0 stays 0
+                const float* p = img + (int64_t)r * attrs;
+                const float t0 = p[5 + (lane < num_class ? lane : 0)], t1 = p[5 + (lane + 64 < num_class ? lane + 64 : 0)];
+                v0[q] = lane < num_class ? t0 : -INFINITY;
+                v1[q] = lane + 64 < num_class ? t1 : -INFINITY;
+                bx[q] = f32x4{p[0], p[1], p[2], p[3]}; ob[q] = p[4];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

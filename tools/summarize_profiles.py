@@ -60,6 +60,21 @@ def main():
                 json.dump(json.loads(line), open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
             else:
                 shutil.copy(p, os.path.join(out, f"{tag}_{name}"))
+    for name, dst in (("bench_416.log", "bench_416.json"), ("bench_fp32.log", "bench_fp32.json")):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+            if lines:
+                json.dump(json.loads(lines[-1]), open(os.path.join(out, f"{tag}_{dst}"), "w"), indent=1)
+    if os.path.isdir(os.path.join(src, "sq")):                   # SQ counters of the band kernels (tools/pmc_summary.py)
+        import subprocess
+        txt = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_summary.py"), os.path.join(src, "sq"), "conv_band"],
+                             capture_output=True, text=True).stdout
+        if txt.strip():
+            open(os.path.join(out, f"{tag}_sq_counters_band.txt"), "w").write(txt)
+    final = os.path.join(os.path.dirname(src.rstrip("/")), f"final_{tag}", "pytest.log")
+    if os.path.exists(final):
+        shutil.copy(final, os.path.join(out, f"{tag}_gpu_pytest.log"))
     # traffic.json consumed by bench.py: keyed by the exact kernel names rocprofv3 reports
     json.dump({"source": f"profiles/{tag}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py with the timing run's tile "
                          "table installed (2 * FETCH_SIZE + WRITE_SIZE per launch, equal launch counts in both passes); not measured in this run",
