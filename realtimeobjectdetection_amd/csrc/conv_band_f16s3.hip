@@ -401,6 +401,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __syncthreads();
 
     RTOD_STAMP(0)                                              // 0: prologue
+    // Main loop above epilogues in the issue arbitration (back to 0 after the drain): -1.2...1.5 % on every band layer class on
+    // one box, -0.1...0.5 % on another (tools/exp_ab_libs.py, profiles/experiments/r03_loop_priority_ab.log); levels 1 and 3 the same,
+    // the same two lines in the generic and ring kernels nothing.
+    __builtin_amdgcn_s_setprio(2);
     int tap = 0, cc = 0;
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
@@ -455,6 +459,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     RTOD_STAMP(6)                                              // 6: drain
+    __builtin_amdgcn_s_setprio(0);
 
 #ifdef RTOD_DIAG
     if (a.dbg & 4) return;
