@@ -216,11 +216,13 @@ def roofline_from_launches(model, x, steps):
     from realtimeobjectdetection_amd import _ffi
     infos = model.launch_infos()
     B = x.size(0)
-    tot = np.zeros(len(infos), dtype=np.float64)
+    runs = []
     for _ in range(steps):
         _, ms = model.forward_timed(x)
-        tot += ms
-    tot /= steps
+        runs.append(np.asarray(ms, dtype=np.float64))
+    runs = np.stack(runs)
+    tot = runs.mean(axis=0)                              # the roofline figures are averages, as the contract asks
+    med = np.median(runs, axis=0)                        # per-layer table: also the median (one stalled replay moves a 20-sample mean by 2x)
     lib = _ffi.lib()
     groups = {}
     for idx, (li, ms) in enumerate(zip(infos, tot)):
@@ -237,10 +239,10 @@ def roofline_from_launches(model, x, steps):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     conv_ms = sum(v["ms"] for v in groups.values())
     per_layer = [{"layer": li.layer, "kind": li.kind, "variant": li.variant, "k": li.ksize, "s": li.stride, "cin": li.cin,
-                  "cout": li.cout, "hout": li.hout, "ms": round(float(ms), 5),
+                  "cout": li.cout, "hout": li.hout, "ms": round(float(ms), 5), "ms_median": round(float(md), 5),
                   "tflops": round(float(li.flops_per_frame) * B / (float(ms) * 1e-3) / 1e12, 2) if li.kind == 0 and ms > 0 else None,
                   "gbs": round((float(li.bytes_per_frame) * B + li.weight_bytes) / (float(ms) * 1e-3) / 1e9, 1) if ms > 0 else None}
-                 for li, ms in zip(infos, tot)]
+                 for li, ms, md in zip(infos, tot, med)]
     # the pointwise (1x1, stride 1) group: HBM-bound by algorithmic bytes (north star: achieved GB/s on the 1x1 convs)
     pw = [(li, ms) for li, ms in zip(infos, tot) if li.kind == 0 and li.ksize == 1 and li.flops_per_frame > 0]
     pw_ms = sum(float(ms) for _, ms in pw)
