@@ -937,7 +937,7 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
         std::sort(ranked.begin(), ranked.end());
         const size_t top = std::min<size_t>(3, ranked.size());
         std::vector<float> fin(top, 1e30f);
-        for (int round = 0; round < 3 && !rc; ++round)
+        for (int round = 0; round < 5 && !rc; ++round)                                 // (five rounds: the top three usually sit within 1-2 % of one another)
             for (size_t t = 0; t < top && !rc; ++t) {
                 float ms; rc = time_variant(ranked[t].second, 2, 4, ms);
                 fin[t] = std::min(fin[t], ms);
