@@ -589,6 +589,7 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
 int conv_band_layer_kg(int cin, int h, int w) { return (cin % 64 == 0 && cin >= 512 && h * w <= 400) ? 2 : 1; }
 bool conv_band_mode_valid(int mode, int cin, int h, int w) {
     if (mode < 0 || mode >= BAND_MODES) return false;
+    if (mode >= BAND_LDS_MODES) return conv_bandd_mode_kg(mode - BAND_LDS_MODES) == conv_band_layer_kg(cin, h, w);
     return (mode >= BAND_K2_MODE0 ? 2 : 1) == conv_band_layer_kg(cin, h, w);
 }
 int conv_band_default_mode(int cin, int h, int w) { return conv_band_layer_kg(cin, h, w) == 2 ? BAND_K2_MODE0 : 0; }
@@ -605,10 +606,11 @@ bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in) {
     X(7, 96, 128, 2, 4, 4, 2, ",k2") X(8, 128, 128, 4, 2, 4, 2, ",k2") X(9, 64, 128, 2, 4, 4, 2, ",k2") X(10, 128, 64, 4, 2, 4, 2, ",k2")
 
 #define RTOD_X_INFO(mode, bm, bn, nwm, nwn, minw, kg, sfx) {bm, bn, "conv_band_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
-static const ConvVariantInfo kBandModes[BAND_MODES] = { RTOD_BAND_TILES(RTOD_X_INFO) };
+static const ConvVariantInfo kBandModes[BAND_LDS_MODES] = { RTOD_BAND_TILES(RTOD_X_INFO) };
 #undef RTOD_X_INFO
 
 int conv_band_kernel_name(int mode, int epi, char* buf, size_t len) {
+    if (mode >= BAND_LDS_MODES) return conv_bandd_kernel_name(mode - BAND_LDS_MODES, epi, buf, len);
 #define RTOD_X_NAME(m, bm, bn, nwm, nwn, minw, kg, sfx) \
     if (mode == m) return snprintf(buf, len, "void rtod::conv_band_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #kg ">(rtod::ConvArgs, int, int)", epi);
     RTOD_BAND_TILES(RTOD_X_NAME)
@@ -616,9 +618,13 @@ int conv_band_kernel_name(int mode, int epi, char* buf, size_t len) {
     return -1;
 }
 
-const ConvVariantInfo& conv_band_mode_info(int mode) { return kBandModes[mode < 0 || mode >= BAND_MODES ? 0 : mode]; }
+const ConvVariantInfo& conv_band_mode_info(int mode) {
+    if (mode >= BAND_LDS_MODES && mode < BAND_MODES) return conv_bandd_mode_info(mode - BAND_LDS_MODES);
+    return kBandModes[mode < 0 || mode >= BAND_LDS_MODES ? 0 : mode];
+}
 
 int launch_conv_band_f16s3(const ConvArgs& a_in, int mode, hipStream_t s) {
+    if (mode >= BAND_LDS_MODES && mode < BAND_MODES) return launch_conv_bandd_f16s3(a_in, mode - BAND_LDS_MODES, s);
     ConvArgs a = a_in;
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_band: null pointer"); return RTOD_E_ARG; }
     if (!conv_band_supported(a.kh, a.stride, a.pad, a.Cin, a.Wi) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled) {

@@ -1,0 +1,476 @@
+// 3x3 / stride 1 / pad 1 convolution, LDS-resident input band + weight fragments straight from global memory
+// (split-precision f16 MFMA), gfx950.  Round 4.
+//
+// Same contract, band geometry, K order and MFMA order as conv_band_f16s3.hip (reference: conv -> BN -> leaky,
+// src/darknet.py:467-501, shortcut fused, 263-268): every mode of this file is one more tile of the band family and gives the
+// same bits as the others (chunk outer, tap inner; per step al*bh, ah*bl, ah*bh), so the frame-independence rule of
+// conv_band_f16s3.hip holds.
+//
+// What is different.  conv_band_f16s3.hip stages the weight panel of every (chunk, tap) step through LDS: global -> VGPR ->
+// ds_write -> barrier -> ds_read, one workgroup barrier per 24 MFMAs of a wave, and a step's memory phase and MFMA phase do not
+// overlap inside a workgroup (round 3's ablations: the bare MFMA loop is 53 % of the kernel).  But the packed weight planes are
+// ALREADY in MFMA fragment order: [step][Npad][32] f16, so the B operand of a 16-column tile (lane -> row lr, 16-byte chunk
+// lh) is 1 KiB of consecutive bytes.  Here every wave loads its own B fragments with `buffer_load_dwordx4` straight into
+// registers, two steps ahead (three register sets), and owns ALL BM rows of a WN-column strip of the tile, so no two waves of
+// a workgroup load the same weights.  What is left in LDS is the input band, written by LDS-DMA (no staging registers, no
+// ds_write).  Consequences:
+//   * no barrier, no LDS write and no B fragment read inside a channel chunk: a wave runs 9 taps x TM x TN x 3 MFMAs (432 for a
+//     128x32 strip) between two barriers, its A fragments read two 16-row tiles ahead of their products;
+//   * LDS traffic per MFMA drops from 512 B (2 + 4 tiles of 32x64 per 24 MFMAs, plus the staging writes) to 341 B, L1 traffic
+//     stays what it was (every weight byte is loaded once per workgroup, as before);
+//   * LDS per workgroup is the band alone (37 KB at 76x76): 128x128 tiles of FOUR waves fit three to a CU, which puts the 722
+//     tiles of a 76x76x8 layer on 768 slots in ONE round (conv_band: 512 slots, 1.41 rounds, the second one half empty).
+//
+// Band image in LDS: 16-row blocks of 2 KiB, [16 rows x 64 B hi][16 rows x 64 B lo]; inside a 1 KiB piece the 16-byte chunk
+// position of (row, chunk c) is c ^ ((row >> 1) & 3) as in conv_band_f16s3.hip (conflict-free ds_read_b128 at every shift;
+// tools/lds_bank_sim.py: a block boundary is a multiple of 256 B, the bank pattern is that of the contiguous image).  One
+// `buffer_load_dwordx4 ... lds` writes a whole piece (lane l -> 16 bytes at 16 l: row l >> 2, position l & 3; the swizzle is
+// applied on the lane's SOURCE address).  The lo piece sits 1024 B behind the hi piece and the next 16-row tile 2048 B further:
+// both are instruction offsets, so a unit (one 16-row tile of one tap) costs two vector instructions of address work.
+// Out-of-image taps read a zero block, selected per lane from a 9-bit mask per tile, as in conv_band_f16s3.hip.
+//
+// vmcnt bookkeeping (in-order retirement; LDS-DMA counts too).  At the top of every chunk everything this wave has issued is
+// waited for (vmcnt(0): its band pieces, the B sets of the chunk's first two steps), then the barrier, then the next chunk's
+// band pieces are issued (double-buffered band) and step t issues the B set of step t + 2 and, from t = 2 on, waits with
+// vmcnt(2 NB) for its own set (two younger sets stay in flight; that wait also covers the band pieces, issued two steps earlier).
+// Single-buffered band (76x76: three workgroups per CU leave 53 KB each): barrier, DMA, vmcnt(0), barrier at every chunk top;
+// the other two workgroups' waves on the SIMD cover the exposed load.
+#include "conv_f16s3_common.h"
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
+namespace rtod {
+
+constexpr int BANDD_MAX_W = 94;
+__host__ __device__ constexpr int bandd_rows(int bm, int w) { return (bm + 2 * w + 2 + 15) / 16 * 16; }
+
+template <int N> __device__ __forceinline__ void bandd_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 16, "vmcnt literal");
+#define RTOD_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(16)
+#undef RTOD_VMCNT_CASE
+}
+
+// raw buffer load with an instruction offset (the 16-column tile of the strip: j KiB), hidden from the compiler's waitcnt pass
+template <int OFF> __device__ __forceinline__ u32x4 bandd_load_b(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voffset), "s"(rsrc), "s"(soffset), "n"(OFF) : "memory");
+    return v;
+}
+
+// hi and lo piece of one 16-row band block: lane l's 16 bytes land at lds + 16 l (M0 written in the statement that uses it)
+__device__ __forceinline__ void bandd_dma_pair(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soff_hi, unsigned soff_lo, unsigned lds_hi) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, %5, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(soff_hi), "s"(soff_lo), "s"(lds_hi)
+        : "memory", "scc");
+}
+
+template <int TN> __device__ __forceinline__ void bandd_tie(u32x4 (&q)[TN][2]) {
+    static_assert(TN >= 1 && TN <= 2, "strip width");
+    if constexpr (TN == 1) asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]) :: "memory");
+    else asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]) :: "memory");
+}
+
+// ---- epilogue: scale / bias / activation, LDS transpose in passes of RG rows, split-format store (+ residual).
+// Arithmetic and expression shapes are those of conv_f16s3_epilogue (conv_f16s3_common.h): the same bits.  Unlike that
+// function a pass may cover a PART of a wave's rows (a wave owns all BM rows of its strip; the whole tile would need 64 KB).
+template <int BM, int BN, int WM, int WN, int NT, int RG, bool RES, int KG>
+__device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem, int bm, int bn, int tid,
+                                               int wm, int wn, int lr, int lh, int M, int kg) {
+    constexpr int TM = WM / 16, TN = WN / 16, MT = 16, NE = 4, TS = BN;
+    static_assert(BM % RG == 0 && RG % 16 == 0, "epilogue pass");
+    float* T = reinterpret_cast<float*>(smem);
+    float amax = 0.f;
+    const float escale = SPLIT_SCALE;
+    constexpr int GPR = BN / 8;
+    constexpr int NG = (RG * GPR + NT - 1) / NT;
+#pragma unroll
+    for (int rg = 0; rg < BM; rg += RG) {
+        float bias_j[TN], inv_j[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn * BN + wn * WN + j * MT + lr;
+            const int nc = n < a.Cout ? n : 0;
+            const float b = a.bias[nc], iv = a.inv_scale[nc];
+            bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
+        }
+        f16x8 rq_h[RES ? NG : 1], rq_l[RES ? NG : 1];
+        if constexpr (RES) {
+            const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int g = tid + i * NT;
+                const int r = g / GPR, c8 = (g - r * GPR) * 8;
+                const int m = bm * BM + rg + r;
+                const bool ok = g < RG * GPR && m < M && bn * BN + c8 < a.Cout;
+                const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
+                const f16x8 th = *reinterpret_cast<const f16x8*>(q), tl = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
+                rq_h[i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        if constexpr (KG == 2) {                                         // K group 1 deposits its raw sums, group 0 adds its own
+            if (kg == 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r0 = wm * WM + i * MT;
+                    if (r0 >= rg && r0 < rg + RG) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) T[(r0 - rg + e + 4 * lh) * TS + wn * WN + j * MT + lr] = acc[i][j][e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (KG == 1 || kg == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WN + j * MT + lr;
+                const float bias = bias_j[j] * escale, inv = inv_j[j] * escale;
+                auto col = [&](auto act) {                                   // 0 linear, 1 leaky, 2 SiLU
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int r0 = wm * WM + i * MT;
+                        if (r0 >= rg && r0 < rg + RG) {                       // compile-time for one wave along M
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) {
+                                const int rl = r0 - rg + e + 4 * lh;
+                                float s = acc[i][j][e];
+                                if constexpr (KG == 2) s += T[rl * TS + nl];
+                                float v = s * inv + bias;
+                                if constexpr (decltype(act)::value == 2) v = silu_scaled(v, 1.0f / escale);
+                                else if constexpr (decltype(act)::value == 1) v = __builtin_fmaxf(v, v * 0.1f);
+                                T[rl * TS + nl] = v;
+                            }
+                        }
+                    }
+                };
+                if (a.leaky == 2) col(std::integral_constant<int, 2>{});
+                else if (a.leaky) col(std::integral_constant<int, 1>{});
+                else col(std::integral_constant<int, 0>{});
+            }
+        }
+        __syncthreads();
+        _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = tid + gi * NT;
+            if (g >= RG * GPR) continue;
+            const int r = g / GPR, c8 = (g - r * GPR) * 8;
+            const int m = bm * BM + rg + r;
+            if (m >= M || bn * BN + c8 >= a.Cout) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * TS + c8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if constexpr (RES) {
+                const f16x8 qh = rq_h[gi], ql = rq_l[gi];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
+            }
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f16(v[e], h, l, amax); ph[e] = h; pl[e] = l; }
+            _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
+            store_act16(q, ph, false);
+            store_act16(q + a.out_ldc, pl, false);
+        }
+        if (rg + RG < BM) __syncthreads();
+    }
+    split_overflow_report(a.ovf, amax);
+}
+
+// BM x BN workgroup tile; NWM x NWN waves per K group, each wave a (BM/NWM) x (BN/NWN) strip (NWM = 1: no weight byte is
+// loaded twice in a workgroup).  DB: double-buffered band.  KG = 2: two wave groups on the even / odd channel chunks (own band
+// buffers), summed in the epilogue — the split-K layers of conv_band_f16s3.hip (conv_band_layer_kg), same summation order.
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, bool DB, int KG>
+__global__ __launch_bounds__(NWM * NWN * 64 * KG, MINW)
+void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
+    constexpr int WM = BM / NWM, WN = BN / NWN, NW = NWM * NWN, NT = NW * 64;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
+    constexpr int TM = WM / 16, TN = WN / 16;
+    static_assert(TN <= 2, "strip width: 16 or 32 columns (instruction offsets, tie)");
+    constexpr int NB = 2 * TN;                                  // B loads of one step
+    constexpr int UNITS = 9 * TM;                               // (tap, 16-row tile) units of one channel chunk
+    constexpr int NBLK_MAX = bandd_rows(BM, BANDD_MAX_W) / 16;
+    constexpr int PPW = (NBLK_MAX + NW - 1) / NW;               // band blocks per wave, at most
+    constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;   // epilogue rows per pass (<= 32 KB of fp32)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.Wi, H = a.Hi;
+    const int NBLK = bandd_rows(BM, W) / 16;
+    const int BUF = (NBLK + 1) * 2048;                          // one band buffer: NBLK blocks + the zero block
+    const int zero_off = NBLK * 2048;
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
+    const int gbase = kg * (DB ? 2 : 1) * BUF;                  // this K group's band buffers
+
+    const int nwg = grid_m * grid_n;
+    int bid = blockIdx.x;
+    if (!a.xcd_by_n) {                                          // XCD x (= blockIdx % 8) takes a contiguous range of tiles
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int bm = bid / grid_n, bn = bid - bm * grid_n;
+
+    const int tid = KG == 1 ? (int)threadIdx.x : (int)threadIdx.x - kg * NT;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = NWM == 1 ? 0 : wave / NWN, wn = NWM == 1 ? wave : wave - wm * NWN;     // NWM == 1: wm is a compile-time 0 (epilogue passes)
+    const int lr = lane & 15, lh = lane >> 4;
+    const int M = a.B * H * W;
+    const int m0 = bm * BM;
+    const int NBv = BM + 2 * W + 2;                             // band rows that can hold a pixel
+    const unsigned PS = (unsigned)a.in_ldc * 4u;
+    const unsigned lo_plane = (unsigned)a.in_ldc * 2u;
+
+    // zero blocks (hi row 0 and lo row 0 of the block behind the band), every buffer of every group
+    if (threadIdx.x < 8 * (DB ? 2 : 1) * KG) {
+        const int b = threadIdx.x >> 3, k = threadIdx.x & 7;
+        *reinterpret_cast<u32x4*>(smem + b * BUF + zero_off + (k >> 2) * 1024 + (k & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- band DMA: block = wave + k NW; lane -> row lane >> 2 of the block, position lane & 3 <- source chunk (lane & 3) ^ swizzle(row)
+    // (per-block source offsets are recomputed at every chunk top from two registers: held in registers across the main loop they
+    //  were the first thing the allocator spilled)
+    const int dma_lrow = lane >> 2;
+    const unsigned dma_cpart = (unsigned)(a.in_coff + ((lane & 3) ^ ((dma_lrow >> 1) & 3)) * 8) * 2u;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto dma_band = [&](int cc, int buf) __attribute__((always_inline)) {       // channel chunk cc of this group -> band buffer buf
+        const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
+        const unsigned base = lds0 + (unsigned)(gbase + buf * BUF);
+        int r0 = wave * 16 + dma_lrow;
+        asm volatile("" : "+v"(r0));                            // not loop-invariant: see above
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int blk = wave + k * NW;
+            const int r = r0 + k * NW * 16;
+            const int q = m0 - W - 1 + r;
+            const unsigned vo = (r < NBv && (unsigned)q < (unsigned)M) ? (unsigned)q * PS + dma_cpart : OOB;
+            if (blk < NBLK) bandd_dma_pair(rs_a, vo, soff, lo_plane + soff, base + (unsigned)blk * 2048u);
+        }
+    };
+
+    // ---- B fragments: lane (lr, lh) <- weight row n0 + 16 j + lr, 16-byte chunk lh of the step's panel; 3 register sets
+    const int n0 = bn * BN + wn * WN;
+    const unsigned bvoff = n0 + lr < a.Npad ? (unsigned)((n0 + lr) * 32 + lh * 8) * 2u : OOB;     // Npad % 128 == 0: a strip is inside or outside
+    const unsigned wchunk = (unsigned)a.Npad * (HBK * 2);       // bytes of one (chunk, tap) panel of a weight plane
+    const int n_cc = a.Cin / 32 / KG;                           // channel chunks of this group: kg, kg + KG, ...
+    const int nsteps = 9 * n_cc;
+    u32x4 Bq[3][TN][2];
+    int ld_step = 0, ld_cc = 0, ld_tap = 0;                     // step whose B set is loaded next: local index, chunk, tap
+    auto load_b = [&](u32x4 (&q)[TN][2]) __attribute__((always_inline)) {
+        const unsigned vo = ld_step < nsteps ? bvoff : OOB;
+        const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * wchunk;
+        q[0][0] = bandd_load_b<0>(rs_wh, vo, koff);
+        q[0][1] = bandd_load_b<0>(rs_wl, vo, koff);
+        if constexpr (TN == 2) {
+            q[1][0] = bandd_load_b<1024>(rs_wh, vo, koff);
+            q[1][1] = bandd_load_b<1024>(rs_wl, vo, koff);
+        }
+        ++ld_step;
+        if (++ld_tap == 9) { ld_tap = 0; ++ld_cc; }
+    };
+
+    // ---- per-lane validity of the 9 taps for the TM 16-row tiles (9 bits per tile, three tiles per register)
+    constexpr int NVM = (TM + 2) / 3;
+    unsigned vmw[NVM];
+    {
+#pragma unroll
+        for (int w = 0; w < NVM; ++w) vmw[w] = 0u;
+        const int hw = H * W;
+        int m = m0 + wm * WM + lr;
+        const int mm = m < M ? m : 0;
+        int b = mm / hw;
+        int r = mm - b * hw;
+        int oy = r / W, ox = r - oy * W;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            unsigned vm = 0;
+            if (m < M) {
+                const unsigned xm = (ox >= 1 ? 1u : 0u) | 2u | (ox + 1 < W ? 4u : 0u);
+                vm = (oy >= 1 ? xm : 0u) | (xm << 3) | (oy + 1 < H ? xm << 6 : 0u);
+            }
+            vmw[i / 3] |= vm << ((i % 3) * 9);
+            m += 16; ox += 16;
+            while (ox >= W) { ox -= W; ++oy; }
+            while (oy >= H) { oy -= H; ++b; }
+        }
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    // ---- A fragments.  Unit (t, i): rows prow0 + 16 i + shift(t) of the band.  x0(t): LDS offset of tile 0's row of this lane.
+    const int prow0 = wm * WM + lr;
+    const int lh4 = lh << 4;
+    f16x8 Ah[3], Al[3];
+    // prow_c / vmw are laundered through an empty asm at every chunk top — left loop-invariant, the 9 TM unit addresses are
+    // hoisted out of the chunk loop and spilled (72 scratch reloads, each behind a vmcnt(0), in the main loop)
+    typedef const f16x8 __attribute__((address_space(3))) lds_f16x8;
+    int prow_c = prow0;
+    auto read_unit = [&](int t, int i, int bufoff, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+        const int row = prow_c + (t / 3) * W + (t % 3);
+        const int x0 = (((row & ~15) << 7) | ((row & 15) << 6) | (((row << 3) ^ lh4) & 0x30)) + bufoff;
+        // o = tap valid ? x0 : zero block.  Written as a ternary it becomes a divergent branch per unit, as (x0 & sel) | (z & ~sel) five
+        // vector instructions; bit-field extract + v_bfi_b32 is two
+        const int sel = __builtin_amdgcn_sbfe((int)vmw[i / 3], (i % 3) * 9 + t, 1);     // 0 or -1
+        const int z = bufoff + zero_off - 2048 * i;
+        int o;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(o) : "v"(sel), "v"(x0), "s"(z));
+        h = *reinterpret_cast<lds_f16x8*>((unsigned)(o + 2048 * i));
+        l = *reinterpret_cast<lds_f16x8*>((unsigned)(o + 2048 * i + 1024));
+    };
+
+    // ---- prologue: band chunk 0, B sets of steps 0 and 1
+    dma_band(0, 0);
+    load_b(Bq[0]);
+    load_b(Bq[1]);
+    __syncthreads();                                            // zero blocks written (drains this wave's loads as well)
+
+    __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+    for (int cc = 0; cc < n_cc; ++cc) {
+        const int buf = DB ? (cc & 1) : 0;
+        const int bufoff = (int)lds0 + gbase + buf * BUF;
+        asm volatile("" : "+v"(prow_c));
+#pragma unroll
+        for (int w = 0; w < NVM; ++w) asm volatile("" : "+v"(vmw[w]));
+        // ---- chunk top: everything issued so far has landed; band(cc) complete in every wave's view
+        if constexpr (!DB) {
+            if (cc > 0) {
+                __builtin_amdgcn_s_barrier();                   // every wave has read its last fragments of chunk cc - 1
+                dma_band(cc, 0);
+            }
+        }
+        bandd_wait_vmcnt<0>();
+        bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if constexpr (DB) { if (cc + 1 < n_cc) dma_band(cc + 1, buf ^ 1); }
+        read_unit(0, 0, bufoff, Ah[0], Al[0]);
+        if constexpr (UNITS > 1) read_unit(1 / TM, 1 % TM, bufoff, Ah[1], Al[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int t = u / TM, i = u % TM;
+            if (i == 0) {                                       // step head: B set of step t + 2, wait for this step's
+                load_b(Bq[(t + 2) % 3]);
+                if (t >= 2) { bandd_wait_vmcnt<2 * NB>(); bandd_tie<TN>(Bq[t % 3]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (u + 2 < UNITS) read_unit((u + 2) / TM, (u + 2) % TM, bufoff, Ah[(u + 2) % 3], Al[(u + 2) % 3]);
+            const f16x8 ah = Ah[u % 3], al = Al[u % 3];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, Bq[t % 3][j][0]), bl = __builtin_bit_cast(f16x8, Bq[t % 3][j][1]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // drain: the two trailing (out-of-range) B sets' registers stay allocated until they have landed
+    bandd_wait_vmcnt<0>();
+    bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]); bandd_tie<TN>(Bq[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
+
+    bandd_epilogue<BM, BN, WM, WN, NT * KG, RG, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+}
+
+template <int BM, int BN, int NWM, int NWN, int MINW, bool DB, int KG>
+static int launch_bandd(const ConvArgs& a, hipStream_t s) {
+    constexpr int NT = NWM * NWN * 64 * KG;
+    constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;
+    const int M = a.B * a.Ho * a.Wo;
+    const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
+    if (a.Cin % (32 * KG)) { set_error("launch_conv_bandd: Cin=%d not a multiple of %d", a.Cin, 32 * KG); return RTOD_E_ARG; }
+    ConvArgs ax = a;
+    ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
+    const int main_bytes = KG * (DB ? 2 : 1) * (bandd_rows(BM, a.Wi) / 16 + 1) * 2048;
+    const int epi_bytes = RG * BN * 4;
+    const int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    if (lds > 160 * 1024) { set_error("launch_conv_bandd: %d bytes of LDS", lds); return RTOD_E_ARG; }
+    auto k_res = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, DB, KG>;
+    auto k_plain = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, DB, KG>;
+    static std::atomic<unsigned long long> attr_done{0};       // per instantiation, one bit per device; > 64 KiB of dynamic LDS needs the opt-in
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_bandd_f16s3 hipGetDevice");
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        const int cap = KG * (DB ? 2 : 1) * (bandd_rows(BM, BANDD_MAX_W) / 16 + 1) * 2048;
+        const int mx = cap > epi_bytes ? cap : epi_bytes;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+            return hip_fail(hipGetLastError(), "conv_bandd_f16s3 LDS attribute");
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NT), lds, s, ax, gm, gn);
+    else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NT), lds, s, ax, gm, gn);
+    return hip_fail(hipGetLastError(), "conv_bandd_f16s3 launch");
+}
+
+// One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
+//   X(index, BM, BN, waves along M, waves along N, MINW, double-buffered band, K groups, name suffix)
+#define RTOD_BANDD_TILES(X) \
+    X(0, 128, 128, 1, 4, 3, false, 1, "") X(1, 128, 128, 1, 4, 3, true, 1, ",db") X(2, 64, 128, 1, 4, 4, true, 1, ",db") X(3, 128, 64, 1, 4, 4, true, 1, ",db") \
+    X(4, 64, 128, 1, 4, 4, true, 2, ",db,k2") X(5, 128, 64, 1, 4, 4, true, 2, ",db,k2") X(6, 128, 128, 1, 4, 2, true, 2, ",db,k2")
+
+#define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
+static const ConvVariantInfo kBanddModes[BANDD_MODES] = { RTOD_BANDD_TILES(RTOD_X_INFO) };
+#undef RTOD_X_INFO
+const ConvVariantInfo& conv_bandd_mode_info(int idx) { return kBanddModes[idx < 0 || idx >= BANDD_MODES ? 0 : idx]; }
+int conv_bandd_mode_kg(int idx) {
+#define RTOD_X_KG(i, bm, bn, nwm, nwn, minw, db, kg, sfx) if (idx == i) return kg;
+    RTOD_BANDD_TILES(RTOD_X_KG)
+#undef RTOD_X_KG
+    return 0;
+}
+
+int conv_bandd_kernel_name(int idx, int epi, char* buf, size_t len) {
+#define RTOD_X_NAME(i, bm, bn, nwm, nwn, minw, db, kg, sfx) \
+    if (idx == i) return snprintf(buf, len, "void rtod::conv_bandd_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #db ", " #kg ">(rtod::ConvArgs, int, int)", epi);
+    RTOD_BANDD_TILES(RTOD_X_NAME)
+#undef RTOD_X_NAME
+    return -1;
+}
+
+int launch_conv_bandd_f16s3(const ConvArgs& a, int idx, hipStream_t s) {
+    if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_bandd: null pointer"); return RTOD_E_ARG; }
+    if (!conv_band_supported(a.kh, a.stride, a.pad, a.Cin, a.Wi) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled || a.pw_wh) {
+        set_error("launch_conv_bandd: unsupported shape (k=%d s=%d pad=%d Cin=%d W=%d)", a.kh, a.stride, a.pad, a.Cin, a.Wi); return RTOD_E_ARG;
+    }
+    if (a.in_ldc % 8 || a.in_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin || a.Npad % 128) { set_error("launch_conv_bandd: bad view / K"); return RTOD_E_ARG; }
+    if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_bandd: buffer extents"); return RTOD_E_ARG; }
+    if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_bandd: input view exceeds its buffer"); return RTOD_E_ARG; }
+    switch (idx) {
+#define RTOD_X_CASE(i, bm, bn, nwm, nwn, minw, db, kg, sfx) case i: return launch_bandd<bm, bn, nwm, nwn, minw, db, kg>(a, s);
+        RTOD_BANDD_TILES(RTOD_X_CASE)
+#undef RTOD_X_CASE
+    }
+    set_error("launch_conv_bandd: mode %d unsupported", idx);
+    return RTOD_E_ARG;
+}
+
+}  // namespace rtod
