@@ -420,7 +420,7 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_bandd_f16s3 hipGetDevice");
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         const int cap = KG * (DB ? 2 : 1) * (bandd_rows(BM, BANDD_MAX_W) / 16 + 1) * 2048;
-        const int mx = cap > epi_bytes ? cap : epi_bytes;
+        const int mx = std::min(cap > epi_bytes ? cap : epi_bytes, 160 * 1024);    // (a launch that needs more is refused above)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return hip_fail(hipGetLastError(), "conv_bandd_f16s3 LDS attribute");
