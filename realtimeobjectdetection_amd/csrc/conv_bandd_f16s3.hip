@@ -39,10 +39,23 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <vector>
+#include <algorithm>
 
 namespace rtod {
 
 constexpr int BANDD_MAX_W = 94;
+
+// Diagnostic build only (make timeline -> librtod_tl.so, -DRTOD_TIMELINE): per workgroup (wave 0) wall clock at start / end and shader
+// cycles spent in: prologue, chunk tops (arrival -> barrier passed), chunk bodies, drain, epilogue.  The product library compiles none of it.
+#ifdef RTOD_TIMELINE
+constexpr int BD_TL_BLOCKS = 2048, BD_TL_N = 8;
+__device__ unsigned long long g_bandd_tl[BD_TL_BLOCKS * BD_TL_N];
+#define BD_STAMP(slot) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tl_[slot] += tn_ - tl_prev_; tl_prev_ = tn_; }
+#else
+#define BD_STAMP(slot)
+#endif
 __host__ __device__ constexpr int bandd_rows(int bm, int w) { return (bm + 2 * w + 2 + 15) / 16 * 16; }
 
 template <int N> __device__ __forceinline__ void bandd_wait_vmcnt() {
@@ -51,6 +64,27 @@ template <int N> __device__ __forceinline__ void bandd_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(16)
 #undef RTOD_VMCNT_CASE
+}
+
+// wait for all but the NBASE + 2 n youngest operations, n (0 ... 5) wave-uniform: the band pieces issued after the awaited B set
+template <int NBASE> __device__ __forceinline__ void bandd_wait_vmcnt_plus(int n) {
+    static_assert(NBASE == 4 || NBASE == 8, "two B sets of 2 or 4 loads");
+    asm volatile("" : "+s"(n));                                 // opaque: left visible, the loop-invariant n unswitches the whole chunk loop six ways
+    if constexpr (NBASE == 8) {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    } else {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    }
 }
 
 // raw buffer load with an instruction offset (the 16-column tile of the strip: j KiB), hidden from the compiler's waitcnt pass
@@ -210,6 +244,11 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;   // epilogue rows per pass (<= 32 KB of fp32)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef RTOD_TIMELINE
+    const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_prev_ = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_[5] = {0, 0, 0, 0, 0};               // prologue, chunk tops, chunk bodies, drain, epilogue
+#endif
     const int W = a.Wi, H = a.Hi;
     const int NBLK = bandd_rows(BM, W) / 16;
     const int BUF = (NBLK + 1) * 2048;                          // one band buffer: NBLK blocks + the zero block
@@ -250,6 +289,10 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
     const unsigned lds0 = (unsigned)(size_t)smem;
+    // Every wave issues the SAME number of pieces, n_dma = ceil(NBLK / NW) pairs (the counted waits of the steps behind a DMA
+    // need it): a wave whose block index runs past the band writes zeros (out-of-range source) into the zero block instead.
+    const int n_dma = (NBLK + NW - 1) / NW;
+    static_assert(PPW <= 5, "bandd_wait_vmcnt_plus covers 5 pairs");
     auto dma_band = [&](int cc, int buf) __attribute__((always_inline)) {       // channel chunk cc of this group -> band buffer buf
         const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
         const unsigned base = lds0 + (unsigned)(gbase + buf * BUF);
@@ -260,8 +303,8 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             const int blk = wave + k * NW;
             const int r = r0 + k * NW * 16;
             const int q = m0 - W - 1 + r;
-            const unsigned vo = (r < NBv && (unsigned)q < (unsigned)M) ? (unsigned)q * PS + dma_cpart : OOB;
-            if (blk < NBLK) bandd_dma_pair(rs_a, vo, soff, lo_plane + soff, base + (unsigned)blk * 2048u);
+            const unsigned vo = (blk < NBLK && r < NBv && (unsigned)q < (unsigned)M) ? (unsigned)q * PS + dma_cpart : OOB;
+            if (k < n_dma) bandd_dma_pair(rs_a, vo, soff, lo_plane + soff, base + (unsigned)(blk < NBLK ? blk * 2048 : zero_off));
         }
     };
 
@@ -341,12 +384,26 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         l = *reinterpret_cast<lds_f16x8*>((unsigned)(o + 2048 * i + 1024));
     };
 
+    // ---- start stagger.  The tiles of a one-round launch start together and stay phase-locked: every workgroup loads its first
+    // band at the same time (1/4 of the layer's input in one burst), and every workgroup stores its tile at the same time, with
+    // the matrix pipes idle meanwhile.  Delaying the workgroups in slots 1, 2, ... of a CU (HW_ID.TG_ID) shifts their memory
+    // phases under the other slots' MFMA phases.
+    if (a.stagger > 0) {
+        const int slot = (int)((__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11))) & 15u);       // HW_ID[19:16] = TG_ID
+        for (int i = (slot % 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);              // 16 x 64 cycles
+    }
     // ---- prologue: band chunk 0, B sets of steps 0 and 1
     dma_band(0, 0);
     load_b(Bq[0]);
     load_b(Bq[1]);
-    __syncthreads();                                            // zero blocks written (drains this wave's loads as well)
+    if constexpr (DB) {                                         // band(0) landed (the chunk tops of the double-buffered loop wait for nothing)
+        bandd_wait_vmcnt<0>();
+        bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                            // zero blocks written
 
+    BD_STAMP(0)
     __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
     for (int cc = 0; cc < n_cc; ++cc) {
@@ -362,11 +419,17 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
                 dma_band(cc, 0);
             }
         }
-        bandd_wait_vmcnt<0>();
-        bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]);
+        // DB: this wave's pieces of band(cc) were issued at the previous chunk top and are older than the B set step 2 of that
+        // chunk waited for: landed.  Nothing is waited for here: the B sets of the next two steps stay in flight across the barrier.
+        int dma_behind = 0;                                     // band pairs issued between B(s + 1) and B(s + 2) of this chunk's first step
+        if constexpr (!DB) {
+            bandd_wait_vmcnt<0>();
+            bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if constexpr (DB) { if (cc + 1 < n_cc) dma_band(cc + 1, buf ^ 1); }
+        if constexpr (DB) { if (cc + 1 < n_cc) { dma_band(cc + 1, buf ^ 1); dma_behind = n_dma; } }
+        BD_STAMP(1)
         read_unit(0, 0, bufoff, Ah[0], Al[0]);
         if constexpr (UNITS > 1) read_unit(1 / TM, 1 % TM, bufoff, Ah[1], Al[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +438,10 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             const int t = u / TM, i = u % TM;
             if (i == 0) {                                       // step head: B set of step t + 2, wait for this step's
                 load_b(Bq[(t + 2) % 3]);
-                if (t >= 2) { bandd_wait_vmcnt<2 * NB>(); bandd_tie<TN>(Bq[t % 3]); }
+                if constexpr (DB) {                             // younger than this step's set: the next two sets and, for t < 2, the band pieces
+                    if (t >= 2) bandd_wait_vmcnt<2 * NB>(); else bandd_wait_vmcnt_plus<2 * NB>(dma_behind);
+                    bandd_tie<TN>(Bq[t % 3]);
+                } else if (t >= 2) { bandd_wait_vmcnt<2 * NB>(); bandd_tie<TN>(Bq[t % 3]); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (u + 2 < UNITS) read_unit((u + 2) / TM, (u + 2) % TM, bufoff, Ah[(u + 2) % 3], Al[(u + 2) % 3]);
@@ -389,6 +455,7 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        BD_STAMP(2)
     }
     // drain: the two trailing (out-of-range) B sets' registers stay allocated until they have landed
     bandd_wait_vmcnt<0>();
@@ -396,8 +463,18 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
+    BD_STAMP(3)
 
     bandd_epilogue<BM, BN, WM, WN, NT * KG, RG, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
+#ifdef RTOD_TIMELINE
+    BD_STAMP(4)
+    if (threadIdx.x == 0 && blockIdx.x < BD_TL_BLOCKS) {
+        unsigned long long* o = g_bandd_tl + blockIdx.x * BD_TL_N;
+        o[0] = tl_start_; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
+        for (int i = 0; i < 5; ++i) o[3 + i] = tl_[i];
+    }
+#endif
 }
 
 template <int BM, int BN, int NWM, int NWN, int MINW, bool DB, int KG>
@@ -409,6 +486,8 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % (32 * KG)) { set_error("launch_conv_bandd: Cin=%d not a multiple of %d", a.Cin, 32 * KG); return RTOD_E_ARG; }
     ConvArgs ax = a;
     ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
+    static const int stagger_env = getenv("RTOD_BD_STAGGER") ? atoi(getenv("RTOD_BD_STAGGER")) : 0;   // experiment knob
+    ax.stagger = stagger_env;
     const int main_bytes = KG * (DB ? 2 : 1) * (bandd_rows(BM, a.Wi) / 16 + 1) * 2048;
     const int epi_bytes = RG * BN * 4;
     const int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
@@ -428,6 +507,50 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     }
     if (a.res) hipLaunchKernelGGL(k_res, dim3(gm * gn), dim3(NT), lds, s, ax, gm, gn);
     else hipLaunchKernelGGL(k_plain, dim3(gm * gn), dim3(NT), lds, s, ax, gm, gn);
+#ifdef RTOD_TIMELINE
+    {   // diagnostic build: synchronises, prints the launch's workgroup timeline
+        static int printed = 0;
+        const int nb = gm * gn < BD_TL_BLOCKS ? gm * gn : BD_TL_BLOCKS;
+        if (printed < 200 && hipDeviceSynchronize() == hipSuccess) {
+            static unsigned long long h[BD_TL_BLOCKS * BD_TL_N];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bandd_tl), sizeof(unsigned long long) * BD_TL_N * nb) == hipSuccess) {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                double ph[5] = {0, 0, 0, 0, 0}, rt = 0, smax = 0, emin = 1e9;
+                for (int b = 0; b < nb; ++b) { if (h[b * BD_TL_N] < t0) t0 = h[b * BD_TL_N]; if (h[b * BD_TL_N + 1] > t1) t1 = h[b * BD_TL_N + 1]; }
+                for (int b = 0; b < nb; ++b) {
+                    for (int i = 0; i < 5; ++i) ph[i] += (double)h[b * BD_TL_N + 3 + i];
+                    rt += (double)(h[b * BD_TL_N + 1] - h[b * BD_TL_N]);
+                    const double st = (h[b * BD_TL_N] - t0) / 100.0, en = (h[b * BD_TL_N + 1] - t0) / 100.0;
+                    if (st > smax) smax = st; if (en < emin) emin = en;
+                }
+                const double cyc = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+                fprintf(stderr, "[timeline] bandd<%d,%d,%dx%d,db%d,k%d> W=%d Cin=%d Cout=%d res=%d wgs=%d lds=%d | span %.1f us | wg mean %.1f us, last start %.1f, first end %.1f | kcycles/wg: prologue %.1f tops %.1f bodies %.1f drain %.1f epilogue %.1f | clock %.0f MHz\n",
+                        BM, BN, NWM, NWN, DB ? 1 : 0, KG, a.Wi, a.Cin, a.Cout, a.res ? 1 : 0, gm * gn, lds, (t1 - t0) / 100.0, rt / nb / 100.0, smax, emin,
+                        ph[0] / nb / 1e3, ph[1] / nb / 1e3, ph[2] / nb / 1e3, ph[3] / nb / 1e3, ph[4] / nb / 1e3, rt > 0 ? cyc / rt * 100.0 : 0.0);
+                if (printed % 11 == 3) {                        // every now and then: the distribution behind the means
+                    std::vector<double> dur(nb), en(nb);
+                    std::map<unsigned long long, int> per_cu;
+                    for (int b = 0; b < nb; ++b) {
+                        dur[b] = (h[b * BD_TL_N + 1] - h[b * BD_TL_N]) / 100.0; en[b] = (h[b * BD_TL_N + 1] - t0) / 100.0;
+                        const unsigned long long w = h[b * BD_TL_N + 2];
+                        ++per_cu[((w >> 32) << 16) | (((w >> 13) & 7) << 8) | ((w >> 12) & 1) << 4 | ((w >> 8) & 15)];     // xcc, se, sh, cu
+                    }
+                    std::sort(dur.begin(), dur.end()); std::sort(en.begin(), en.end());
+                    int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (auto& kv : per_cu) ++hist[kv.second < 7 ? kv.second : 7];
+                    fprintf(stderr, "[timeline]   wg duration us min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | end us p10 %.1f p50 %.1f p90 %.1f max %.1f | CUs seen %d, with 1/2/3/4/5 wgs: %d %d %d %d %d\n",
+                            dur[0], dur[nb / 10], dur[nb / 2], dur[nb * 9 / 10], dur[nb - 1], en[nb / 10], en[nb / 2], en[nb * 9 / 10], en[nb - 1],
+                            (int)per_cu.size(), hist[1], hist[2], hist[3], hist[4], hist[5]);
+                    // per workgroup slot (TG_ID): mean start, mean duration
+                    double ss[16] = {0}, sd[16] = {0}; int sn[16] = {0};
+                    for (int b = 0; b < nb; ++b) { const int tg = (int)((h[b * BD_TL_N + 2] >> 16) & 15); ++sn[tg]; ss[tg] += (h[b * BD_TL_N] - t0) / 100.0; sd[tg] += (h[b * BD_TL_N + 1] - h[b * BD_TL_N]) / 100.0; }
+                    for (int tg = 0; tg < 16; ++tg) if (sn[tg]) fprintf(stderr, "[timeline]   slot %d: %d wgs, mean start %.1f us, mean duration %.1f us\n", tg, sn[tg], ss[tg] / sn[tg], sd[tg] / sn[tg]);
+                }
+                ++printed;
+            }
+        }
+    }
+#endif
     return hip_fail(hipGetLastError(), "conv_bandd_f16s3 launch");
 }
 
@@ -435,7 +558,8 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
 //   X(index, BM, BN, waves along M, waves along N, MINW, double-buffered band, K groups, name suffix)
 #define RTOD_BANDD_TILES(X) \
     X(0, 128, 128, 1, 4, 3, false, 1, "") X(1, 128, 128, 1, 4, 3, true, 1, ",db") X(2, 64, 128, 1, 4, 4, true, 1, ",db") X(3, 128, 64, 1, 4, 4, true, 1, ",db") \
-    X(4, 64, 128, 1, 4, 4, true, 2, ",db,k2") X(5, 128, 64, 1, 4, 4, true, 2, ",db,k2") X(6, 128, 128, 1, 4, 2, true, 2, ",db,k2")
+    X(4, 64, 128, 1, 4, 4, true, 2, ",db,k2") X(5, 128, 64, 1, 4, 4, true, 2, ",db,k2") X(6, 128, 128, 1, 4, 2, true, 2, ",db,k2") \
+    X(7, 96, 128, 1, 4, 3, true, 1, ",db") X(8, 96, 128, 1, 4, 3, true, 2, ",db,k2")
 
 #define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
 static const ConvVariantInfo kBanddModes[BANDD_MODES] = { RTOD_BANDD_TILES(RTOD_X_INFO) };
