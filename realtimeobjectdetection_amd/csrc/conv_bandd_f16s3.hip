@@ -130,31 +130,38 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
     const float escale = SPLIT_SCALE;
     constexpr int GPR = BN / 8;
     constexpr int NG = (RG * GPR + NT - 1) / NT;
+    // every global load of the epilogue up front, for ALL passes: bias / scale of the wave's column tiles, then the residual
+    // operands (vmcnt retires in order: the transpose only has to wait for the first).  Loaded per pass, every pass paid the
+    // memory latency again, between two barriers.
+    constexpr int NP = BM / RG;
+    float bias_j[TN], inv_j[TN];
 #pragma unroll
-    for (int rg = 0; rg < BM; rg += RG) {
-        float bias_j[TN], inv_j[TN];
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn * BN + wn * WN + j * MT + lr;
+        const int nc = n < a.Cout ? n : 0;
+        const float b = a.bias[nc], iv = a.inv_scale[nc];
+        bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
+    }
+    f16x8 rq_h[RES ? NP : 1][RES ? NG : 1], rq_l[RES ? NP : 1][RES ? NG : 1];
+    if constexpr (RES) {
+        const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = bn * BN + wn * WN + j * MT + lr;
-            const int nc = n < a.Cout ? n : 0;
-            const float b = a.bias[nc], iv = a.inv_scale[nc];
-            bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
-        }
-        f16x8 rq_h[RES ? NG : 1], rq_l[RES ? NG : 1];
-        if constexpr (RES) {
-            const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 const int g = tid + i * NT;
                 const int r = g / GPR, c8 = (g - r * GPR) * 8;
-                const int m = bm * BM + rg + r;
+                const int m = bm * BM + p * RG + r;
                 const bool ok = g < RG * GPR && m < M && bn * BN + c8 < a.Cout;
                 const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
                 const f16x8 th = *reinterpret_cast<const f16x8*>(q), tl = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
-                rq_h[i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                rq_l[i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_h[p][i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[p][i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
-        }
+    }
+    __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
+#pragma unroll
+    for (int rg = 0; rg < BM; rg += RG) {
         if constexpr (KG == 2) {                                         // K group 1 deposits its raw sums, group 0 adds its own
             if (kg == 1) {
 #pragma unroll
@@ -211,7 +218,7 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if constexpr (RES) {
-                const f16x8 qh = rq_h[gi], ql = rq_l[gi];
+                const f16x8 qh = rq_h[rg / RG][gi], ql = rq_l[rg / RG][gi];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
             }
@@ -230,9 +237,16 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
 // BM x BN workgroup tile; NWM x NWN waves per K group, each wave a (BM/NWM) x (BN/NWN) strip (NWM = 1: no weight byte is
 // loaded twice in a workgroup).  DB: double-buffered band.  KG = 2: two wave groups on the even / odd channel chunks (own band
 // buffers), summed in the epilogue — the split-K layers of conv_band_f16s3.hip (conv_band_layer_kg), same summation order.
-template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, bool DB, int KG>
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, int BUFM, int KG>
 __global__ __launch_bounds__(NWM * NWN * 64 * KG, MINW)
 void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
+    // BUFM: 0 one band buffer, replaced between two barriers at every chunk top (the load is exposed; other workgroups cover it);
+    //       1 two band buffers, the next chunk's band loads under the current chunk.
+    // (Round 4 also measured a ROLLING band — one buffer replaced in place in three parts as the taps release its rows, every load
+    //  under two steps of MFMAs, three barriers per chunk: bit-identical, 2.6 % SLOWER than BUFM 0 at 76x76; a barrier costs the
+    //  workgroup 1.2-1.8 k cycles of skew, more than the exposed load.  profiles/experiments/r04_bandd_roll_stagger_prio.patch)
+    constexpr bool DB = BUFM == 1;
+    static_assert(BUFM == 0 || BUFM == 1, "band buffering");
     constexpr int WM = BM / NWM, WN = BN / NWN, NW = NWM * NWN, NT = NW * 64;
     static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0, "wave tile");
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -283,8 +297,6 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // ---- band DMA: block = wave + k NW; lane -> row lane >> 2 of the block, position lane & 3 <- source chunk (lane & 3) ^ swizzle(row)
     // (per-block source offsets are recomputed at every chunk top from two registers: held in registers across the main loop they
     //  were the first thing the allocator spilled)
-    const int dma_lrow = lane >> 2;
-    const unsigned dma_cpart = (unsigned)(a.in_coff + ((lane & 3) ^ ((dma_lrow >> 1) & 3)) * 8) * 2u;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
@@ -293,21 +305,25 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // need it): a wave whose block index runs past the band writes zeros (out-of-range source) into the zero block instead.
     const int n_dma = (NBLK + NW - 1) / NW;
     static_assert(PPW <= 5, "bandd_wait_vmcnt_plus covers 5 pairs");
-    auto dma_band = [&](int cc, int buf) __attribute__((always_inline)) {       // channel chunk cc of this group -> band buffer buf
+    // blocks [blk_lo, blk_hi) of channel chunk cc -> band buffer buf, n pairs per wave (n = ceil((blk_hi - blk_lo) / NW), wave-uniform)
+    auto dma_blocks = [&](int cc, int buf, int blk_lo, int blk_hi, int n) __attribute__((always_inline)) {
         const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
         const unsigned base = lds0 + (unsigned)(gbase + buf * BUF);
-        int r0 = wave * 16 + dma_lrow;
-        asm volatile("" : "+v"(r0));                            // not loop-invariant: see above
+        int l = (int)threadIdx.x;
+        asm volatile("" : "+v"(l));                             // not loop-invariant: see above (everything below is recomputed per call)
+        const int dma_lrow = (l & 63) >> 2;
+        const unsigned dma_cpart = (unsigned)(a.in_coff + ((l & 3) ^ ((dma_lrow >> 1) & 3)) * 8) * 2u;
+        const int r0 = (blk_lo + wave) * 16 + dma_lrow;
 #pragma unroll
         for (int k = 0; k < PPW; ++k) {
-            const int blk = wave + k * NW;
+            const int blk = blk_lo + wave + k * NW;
             const int r = r0 + k * NW * 16;
             const int q = m0 - W - 1 + r;
-            const unsigned vo = (blk < NBLK && r < NBv && (unsigned)q < (unsigned)M) ? (unsigned)q * PS + dma_cpart : OOB;
-            if (k < n_dma) bandd_dma_pair(rs_a, vo, soff, lo_plane + soff, base + (unsigned)(blk < NBLK ? blk * 2048 : zero_off));
+            const unsigned vo = (blk < blk_hi && r < NBv && (unsigned)q < (unsigned)M) ? (unsigned)q * PS + dma_cpart : OOB;
+            if (k < n) bandd_dma_pair(rs_a, vo, soff, lo_plane + soff, base + (unsigned)(blk < blk_hi ? blk * 2048 : zero_off));
         }
     };
-
+    auto dma_band = [&](int cc, int buf) __attribute__((always_inline)) { dma_blocks(cc, buf, 0, NBLK, n_dma); };
     // ---- B fragments: lane (lr, lh) <- weight row n0 + 16 j + lr, 16-byte chunk lh of the step's panel; 3 register sets
     const int n0 = bn * BN + wn * WN;
     const unsigned bvoff = n0 + lr < a.Npad ? (unsigned)((n0 + lr) * 32 + lh * 8) * 2u : OOB;     // Npad % 128 == 0: a strip is inside or outside
@@ -384,14 +400,6 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         l = *reinterpret_cast<lds_f16x8*>((unsigned)(o + 2048 * i + 1024));
     };
 
-    // ---- start stagger.  The tiles of a one-round launch start together and stay phase-locked: every workgroup loads its first
-    // band at the same time (1/4 of the layer's input in one burst), and every workgroup stores its tile at the same time, with
-    // the matrix pipes idle meanwhile.  Delaying the workgroups in slots 1, 2, ... of a CU (HW_ID.TG_ID) shifts their memory
-    // phases under the other slots' MFMA phases.
-    if (a.stagger > 0) {
-        const int slot = (int)((__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11))) & 15u);       // HW_ID[19:16] = TG_ID
-        for (int i = (slot % 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);              // 16 x 64 cycles
-    }
     // ---- prologue: band chunk 0, B sets of steps 0 and 1
     dma_band(0, 0);
     load_b(Bq[0]);
@@ -421,7 +429,7 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
         }
         // DB: this wave's pieces of band(cc) were issued at the previous chunk top and are older than the B set step 2 of that
         // chunk waited for: landed.  Nothing is waited for here: the B sets of the next two steps stay in flight across the barrier.
-        int dma_behind = 0;                                     // band pairs issued between B(s + 1) and B(s + 2) of this chunk's first step
+        int dma_behind = 0;                                     // band pairs issued between B(s + 1) and B(s + 2) of the current phase's first step
         if constexpr (!DB) {
             bandd_wait_vmcnt<0>();
             bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]);
@@ -462,7 +470,6 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     bandd_tie<TN>(Bq[0]); bandd_tie<TN>(Bq[1]); bandd_tie<TN>(Bq[2]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
-    __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
     BD_STAMP(3)
 
     bandd_epilogue<BM, BN, WM, WN, NT * KG, RG, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
@@ -477,8 +484,9 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #endif
 }
 
-template <int BM, int BN, int NWM, int NWN, int MINW, bool DB, int KG>
+template <int BM, int BN, int NWM, int NWN, int MINW, int BUFM, int KG>
 static int launch_bandd(const ConvArgs& a, hipStream_t s) {
+    constexpr bool DB = BUFM == 1;
     constexpr int NT = NWM * NWN * 64 * KG;
     constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;
     const int M = a.B * a.Ho * a.Wo;
@@ -486,14 +494,12 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % (32 * KG)) { set_error("launch_conv_bandd: Cin=%d not a multiple of %d", a.Cin, 32 * KG); return RTOD_E_ARG; }
     ConvArgs ax = a;
     ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
-    static const int stagger_env = getenv("RTOD_BD_STAGGER") ? atoi(getenv("RTOD_BD_STAGGER")) : 0;   // experiment knob
-    ax.stagger = stagger_env;
     const int main_bytes = KG * (DB ? 2 : 1) * (bandd_rows(BM, a.Wi) / 16 + 1) * 2048;
     const int epi_bytes = RG * BN * 4;
     const int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     if (lds > 160 * 1024) { set_error("launch_conv_bandd: %d bytes of LDS", lds); return RTOD_E_ARG; }
-    auto k_res = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, DB, KG>;
-    auto k_plain = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, DB, KG>;
+    auto k_res = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, BUFM, KG>;
+    auto k_plain = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, BUFM, KG>;
     static std::atomic<unsigned long long> attr_done{0};       // per instantiation, one bit per device; > 64 KiB of dynamic LDS needs the opt-in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_bandd_f16s3 hipGetDevice");
@@ -525,7 +531,7 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
                 }
                 const double cyc = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
                 fprintf(stderr, "[timeline] bandd<%d,%d,%dx%d,db%d,k%d> W=%d Cin=%d Cout=%d res=%d wgs=%d lds=%d | span %.1f us | wg mean %.1f us, last start %.1f, first end %.1f | kcycles/wg: prologue %.1f tops %.1f bodies %.1f drain %.1f epilogue %.1f | clock %.0f MHz\n",
-                        BM, BN, NWM, NWN, DB ? 1 : 0, KG, a.Wi, a.Cin, a.Cout, a.res ? 1 : 0, gm * gn, lds, (t1 - t0) / 100.0, rt / nb / 100.0, smax, emin,
+                        BM, BN, NWM, NWN, BUFM, KG, a.Wi, a.Cin, a.Cout, a.res ? 1 : 0, gm * gn, lds, (t1 - t0) / 100.0, rt / nb / 100.0, smax, emin,
                         ph[0] / nb / 1e3, ph[1] / nb / 1e3, ph[2] / nb / 1e3, ph[3] / nb / 1e3, ph[4] / nb / 1e3, rt > 0 ? cyc / rt * 100.0 : 0.0);
                 if (printed % 11 == 3) {                        // every now and then: the distribution behind the means
                     std::vector<double> dur(nb), en(nb);
@@ -557,9 +563,10 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
 //   X(index, BM, BN, waves along M, waves along N, MINW, double-buffered band, K groups, name suffix)
 #define RTOD_BANDD_TILES(X) \
-    X(0, 128, 128, 1, 4, 3, false, 1, "") X(1, 128, 128, 1, 4, 3, true, 1, ",db") X(2, 64, 128, 1, 4, 4, true, 1, ",db") X(3, 128, 64, 1, 4, 4, true, 1, ",db") \
-    X(4, 64, 128, 1, 4, 4, true, 2, ",db,k2") X(5, 128, 64, 1, 4, 4, true, 2, ",db,k2") X(6, 128, 128, 1, 4, 2, true, 2, ",db,k2") \
-    X(7, 96, 128, 1, 4, 3, true, 1, ",db") X(8, 96, 128, 1, 4, 3, true, 2, ",db,k2")
+    X(0, 128, 128, 1, 4, 3, 0, 1, "") X(1, 128, 128, 1, 4, 3, 1, 1, ",db") X(2, 64, 128, 1, 4, 4, 1, 1, ",db") \
+    X(3, 64, 128, 1, 4, 4, 1, 2, ",db,k2") X(4, 128, 128, 1, 4, 2, 1, 2, ",db,k2") \
+    X(5, 96, 128, 1, 4, 3, 1, 1, ",db") X(6, 96, 128, 1, 4, 3, 1, 2, ",db,k2")
+// (measured and dropped: 128x64 tiles of 128x16 strips, double-buffered, with and without split-K — 3-9 % behind the 32-column strips on every grid)
 
 #define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
 static const ConvVariantInfo kBanddModes[BANDD_MODES] = { RTOD_BANDD_TILES(RTOD_X_INFO) };
@@ -571,7 +578,6 @@ int conv_bandd_mode_kg(int idx) {
 #undef RTOD_X_KG
     return 0;
 }
-
 int conv_bandd_kernel_name(int idx, int epi, char* buf, size_t len) {
 #define RTOD_X_NAME(i, bm, bn, nwm, nwn, minw, db, kg, sfx) \
     if (idx == i) return snprintf(buf, len, "void rtod::conv_bandd_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #db ", " #kg ">(rtod::ConvArgs, int, int)", epi);

@@ -75,7 +75,6 @@ struct ConvArgs {
     int dbg = 0;                                // timing experiments, diagnostic build only (-DRTOD_STAMPS reads RTOD_DBG_ZERO); the product library never sets or reads it
     int32_t* ovf = nullptr;                     // split-format producers: device word that gets 1 OR-ed in when an activation saturates the f16 range
     int xcd_by_n = 0;                           // split kernels: workgroup -> XCD by output-channel tile instead of by pixel tile (see launch_band)
-    int stagger = 0;                            // conv_bandd_f16s3.hip: start delay per resident-workgroup slot of a CU, in units of 1024 cycles
     int out_split = 0;                          // exact-fp32 kernel only: write the output in the split format
     // exact-fp32 kernel only: K slices (conv_igemm_f32.hip).  slice_chunks > 0: the K sum is formed slice by slice (a property of
     // the layer); partial != nullptr: one workgroup per slice, raw sums to this scratch ([slices][M][Npad] floats), then a reduction
@@ -135,10 +134,11 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 // A layer the band kernel supports ALWAYS runs on it (its split-K layers sum in a different order than the generic kernel, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
-constexpr int BANDD_MODES = 9;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
+constexpr int BANDD_MODES = 7;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
 constexpr int BAND_LDS_MODES = 11;         // conv_band_f16s3.hip: 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
                                            // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2, 64x128/2x4, 128x64/4x2 (13x13 grids)
-constexpr int BAND_MODES = BAND_LDS_MODES + BANDD_MODES;    // modes >= BAND_LDS_MODES: conv_bandd tile (mode - BAND_LDS_MODES)
+constexpr int BAND_MODES = BAND_LDS_MODES + BANDD_MODES;
+static_assert(50 + BAND_MODES <= 70, "band variant ids end where the ring kernel's begin");    // modes >= BAND_LDS_MODES: conv_bandd tile (mode - BAND_LDS_MODES)
 constexpr int BAND_K2_MODE0 = 7;
 const ConvVariantInfo& conv_bandd_mode_info(int idx);
 int conv_bandd_mode_kg(int idx);
