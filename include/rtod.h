@@ -164,6 +164,12 @@ int rtod_plan_read_layer(rtod_plan* plan, int layer, int batch, float* out_dev_n
  * F2).  Per-channel mean and BIASED variance of a conv layer's last forward (host doubles; synchronises `stream`): what the
  * host class needs to update running_mean / running_var like torch does (momentum 0.1, unbiased variance). */
 int rtod_plan_bn_batch_stats(rtod_plan* plan, int layer, double* mean_host, double* var_host, int channels, void* stream);
+/* The side effect itself, for ALL BatchNorm layers of such a plan in ONE launch (no host round trip): after a forward of `batch`
+ * frames, running_mean[k] = (1 - momentum) * running_mean[k] + momentum * batch mean, running_var[k] likewise with the unbiased
+ * batch variance, in float32 like torch (nn.BatchNorm2d in training mode, src/darknet.py:493-495).  running_mean_dev /
+ * running_var_dev: HOST arrays of n_bn device pointers (float32 [cout]), the plan's BatchNorm layers in cfg order.  Enqueues only. */
+int rtod_plan_bn_update_running(rtod_plan* plan, int batch, float* const* running_mean_dev, float* const* running_var_dev, int n_bn,
+                                double momentum, void* stream);
 
 /* replaces predict_transform                                 src/util.py:175-239
  * raw_dev [batch, A*attrs, G, G] NCHW -> out_dev [batch, G*G*A, attrs]; anchors = A (w,h) pairs

@@ -387,6 +387,36 @@ int launch_bn_batch(const View& x, const View& y, const View* res, int B, double
     return hip_fail(hipGetLastError(), "bn_apply launch");
 }
 
+// Training-mode side effect of nn.BatchNorm2d on its buffers, for ALL BatchNorm layers of a plan in one launch (the host class
+// used to fetch every layer's statistics with a synchronising call and update the module buffers with two small copies each:
+// 72 round trips + 144 copies per forward at YOLOv3).  running = (1 - momentum) * running + momentum * batch statistic in float32,
+// the variance UNBIASED (n / (n - 1)), as torch does (momentum 0.1 by default; src/darknet.py:493-495 builds plain BatchNorm2d).
+// One workgroup per (layer, 256 channels).
+__global__ __launch_bounds__(256)
+void bn_update_running_kernel(BnUpdateTable t, const double* __restrict__ stats, float momentum, double momentum_d) {
+    const BnUpdateEntry e = t.e[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= e.channels) return;
+    const double mean = stats[e.stats_off + c];
+    const double var = stats[e.stats_off + e.sstride + c] * e.unbias;
+    // mul_(1 - momentum) then add_(float32(momentum * statistic)): two rounded float32 operations, no contraction
+    e.running_mean[c] = __fadd_rn(__fmul_rn(e.running_mean[c], 1.0f - momentum), (float)(momentum_d * mean));
+    e.running_var[c] = __fadd_rn(__fmul_rn(e.running_var[c], 1.0f - momentum), (float)(momentum_d * var));
+}
+
+int launch_bn_update_running(const BnUpdateEntry* entries, int n, const double* stats, double momentum, hipStream_t s) {
+    if (!entries || n < 1 || !stats) { set_error("bn_update_running: bad args"); return RTOD_E_ARG; }
+    for (int i0 = 0; i0 < n; i0 += BN_UPDATE_MAX) {
+        BnUpdateTable t;
+        const int m = n - i0 < BN_UPDATE_MAX ? n - i0 : BN_UPDATE_MAX;
+        int cmax = 0;
+        for (int i = 0; i < m; ++i) { t.e[i] = entries[i0 + i]; if (t.e[i].channels > cmax) cmax = t.e[i].channels; }
+        hipLaunchKernelGGL(bn_update_running_kernel, dim3((cmax + 255) / 256, m), dim3(256), 0, s, t, stats, (float)momentum, momentum);
+        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_update_running launch");
+    }
+    return RTOD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // NHWC view -> dense NCHW (test/debug read-back of a layer output)
 __global__ void view_to_nchw_kernel(View in, int B, float* __restrict__ out) {

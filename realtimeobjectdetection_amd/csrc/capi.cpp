@@ -252,6 +252,30 @@ int rtod_plan_bn_batch_stats(rtod_plan* plan, int layer, double* mean_host, doub
     RTOD_GUARD_END
 }
 
+int rtod_plan_bn_update_running(rtod_plan* plan, int batch, float* const* running_mean_dev, float* const* running_var_dev, int n_bn,
+                                double momentum, void* stream) {
+    RTOD_GUARD_BEGIN
+    if (!plan || !running_mean_dev || !running_var_dev || batch < 1 || batch > plan->p.max_batch) { set_error("bn_update_running: bad args"); return RTOD_E_ARG; }
+    if (!plan->p.opt_bn_batch_stats || !plan->p.d_bn_stats) { set_error("bn_update_running: the plan does not run batch-statistics BatchNorm (option bn_batch_stats, weights loaded)"); return RTOD_E_STATE; }
+    std::vector<BnUpdateEntry> ent;
+    for (const auto& pc : plan->p.convs) {                       // cfg order
+        if (pc.stats_off < 0) continue;
+        const int k = (int)ent.size();
+        if (k >= n_bn) { set_error("bn_update_running: %d pointers for more BatchNorm layers", n_bn); return RTOD_E_ARG; }
+        if (!running_mean_dev[k] || !running_var_dev[k]) { set_error("bn_update_running: null buffer %d", k); return RTOD_E_ARG; }
+        const View v = plan->p.view_of(pc.layer);
+        const auto& L = plan->p.layers[pc.layer];
+        const int64_t n = (int64_t)batch * L.hout * L.wout;
+        (void)v;
+        ent.push_back(BnUpdateEntry{running_mean_dev[k], running_var_dev[k], pc.stats_off, (double)n / (double)(n > 1 ? n - 1 : 1), pc.Npad, L.cout});
+    }
+    if ((int)ent.size() != n_bn) { set_error("bn_update_running: the plan has %d BatchNorm layers, %d pointers given", (int)ent.size(), n_bn); return RTOD_E_ARG; }
+    if (ent.empty()) return RTOD_OK;
+    RTOD_HIP(hipSetDevice(plan->p.device));
+    return launch_bn_update_running(ent.data(), (int)ent.size(), plan->p.d_bn_stats, momentum, (hipStream_t)stream);
+    RTOD_GUARD_END
+}
+
 int rtod_predict_transform(const float* raw_dev, int batch, int attrs, int grid, int n_anchors, const float* anchors_wh,
                            int inp_dim, int train, float* out_dev, void* stream) {
     RTOD_GUARD_BEGIN

@@ -188,6 +188,11 @@ int launch_maxpool(const View& in, const View& out, int B, int size, int stride,
 int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_t s);
 // batch-statistics BatchNorm (+ activation + shortcut) over a conv's raw output, in place (aux_kernels.hip); stats: 2*C doubles of scratch
 int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act, hipStream_t s);
+// running_mean / running_var update of every BatchNorm layer of a batch-statistics plan in one launch (aux_kernels.hip)
+struct BnUpdateEntry { float* running_mean; float* running_var; int64_t stats_off; double unbias; int sstride; int channels; };
+constexpr int BN_UPDATE_MAX = 32;                 // entries per launch (by-value kernel argument: 32 x 40 bytes)
+struct BnUpdateTable { BnUpdateEntry e[BN_UPDATE_MAX]; };
+int launch_bn_update_running(const BnUpdateEntry* entries, int n, const double* stats, double momentum, hipStream_t s);
 int launch_copy(const View& in, const View& out, int B, hipStream_t s);
 int launch_view_to_nchw(const View& in, int B, float* out_nchw, hipStream_t s);
 // strided decode: raw element (b, ch, y, x) at raw[b*sb + ch*sc + y*sy + x*sx]

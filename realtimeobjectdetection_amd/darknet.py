@@ -415,34 +415,31 @@ class Darknet(nn.Module):
 
     def _update_running_stats(self, batch, stream):
         """Training-mode side effect of nn.BatchNorm2d (momentum 0.1): running_mean / running_var move towards the batch's mean
-        and UNBIASED variance, num_batches_tracked counts up — the reference mutates them on every forward."""
+        and UNBIASED variance, num_batches_tracked counts up — the reference mutates them on every forward.
+        One kernel launch for all BatchNorm layers (rtod_plan_bn_update_running), no host round trip: the module buffers are
+        updated in place on the device, behind the forward on the same stream."""
         lib = _ffi.lib()
-        changed = False
-        ir = build_ir(self.blocks, int(self.net_info["height"]))
-        for i, (m, blk) in enumerate(zip(self.module_list, self.blocks[1:])):
-            if blk["type"] != "convolutional":
-                continue
-            bn = None
-            for sub in m.children():
-                if isinstance(sub, nn.BatchNorm2d):
-                    bn = sub
-            if bn is None:
-                continue
-            c = bn.num_features
-            mean = np.empty(c, dtype=np.float64)
-            var = np.empty(c, dtype=np.float64)
-            _ffi.check(lib.rtod_plan_bn_batch_stats(self._plan, i, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), c, stream))
-            L = ir.layers[i]
-            n = batch * L.hout * L.wout
-            unbiased = var * (n / max(1, n - 1))
-            mom = bn.momentum if bn.momentum is not None else 0.1
-            with torch.no_grad():
-                bn.running_mean.mul_(1 - mom).add_(torch.from_numpy((mom * mean).astype(np.float32)).to(bn.running_mean.device))
-                bn.running_var.mul_(1 - mom).add_(torch.from_numpy((mom * unbiased).astype(np.float32)).to(bn.running_var.device))
-                bn.num_batches_tracked += 1
-            changed = True
-        if changed:
-            self._stats_version += 1            # an eval-mode plan built later folds the updated statistics
+        bns = [sub for m in self.module_list for sub in m.children() if isinstance(sub, nn.BatchNorm2d)]
+        if not bns:
+            return
+        dev = torch.device("cuda", self._plan_key[2])
+        mom = {bn.momentum if bn.momentum is not None else 0.1 for bn in bns}
+        if len(mom) != 1:
+            raise RuntimeError("Darknet: BatchNorm layers with different momenta are not supported")
+        for bn in bns:                                             # the buffers live where the plan runs (the reference: model.cuda())
+            for name in ("running_mean", "running_var", "num_batches_tracked"):
+                t = getattr(bn, name)
+                if t.device != dev:
+                    setattr(bn, name, t.to(dev))
+            if bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous() or not bn.running_var.is_contiguous():
+                raise RuntimeError("Darknet: BatchNorm running statistics must be contiguous float32 tensors")
+        n = len(bns)
+        rm = (C.c_void_p * n)(*[bn.running_mean.data_ptr() for bn in bns])
+        rv = (C.c_void_p * n)(*[bn.running_var.data_ptr() for bn in bns])
+        with torch.cuda.device(dev):
+            _ffi.check(lib.rtod_plan_bn_update_running(self._plan, int(batch), rm, rv, n, float(mom.pop()), stream))
+            torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        self._stats_version += 1                # an eval-mode plan built later folds the updated statistics
 
     def overflowed(self) -> bool:
         """True when a split-f16 producer saturated since the last call (one small host sync); clears the flag."""

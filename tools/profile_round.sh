@@ -10,6 +10,7 @@ mkdir -p $out
 T=$out/tiles.json
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 set -e
+rm -f $T   # never replay a tile table measured on an older build
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 --tiles $T --layers-out $out/layers.json > $out/bench.log 2> $out/bench.err
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --res 416 --no-cpu-baseline --no-extras > $out/bench_416.log 2>> $out/bench.err
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline --no-extras > $out/bench_fp32.log 2>> $out/bench.err
