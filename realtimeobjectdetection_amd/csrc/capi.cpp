@@ -94,6 +94,7 @@ int rtod_plan_describe(const rtod_plan* plan, char* buf, size_t len, size_t* nee
 const char* rtod_conv_variant_name(int variant) {
     if (variant == 100 + STEM2_VARIANT) return "conv_stem2_f16s3<2 x 4x16, stem + 3x3 s2 + 1x1>";
     if (variant >= 100 + PATCH_VARIANT_BASE && variant < 100 + PATCH_VARIANT_BASE + PATCH_MODES) return conv_patch_mode_info(variant - 100 - PATCH_VARIANT_BASE).name;
+    if (variant >= 100 + PWD_VARIANT_BASE && variant < 100 + PWD_VARIANT_BASE + PWD_MODES) return conv_pwd_mode_info(variant - 100 - PWD_VARIANT_BASE).name;
     if (variant >= 100 + RING_VARIANT_BASE && variant < 100 + RING_VARIANT_BASE + RING_MODES) return conv_ring_mode_info(variant - 100 - RING_VARIANT_BASE).name;
     if (variant >= 100 + BAND_VARIANT_BASE && variant < 100 + BAND_VARIANT_BASE + BAND_MODES) return conv_band_mode_info(variant - 100 - BAND_VARIANT_BASE).name;
     if (variant >= 100 && variant < 100 + HV_COUNT) return conv_f16s3_variant_info(variant - 100).name;
@@ -109,6 +110,7 @@ int rtod_conv_kernel_name(int variant, int epilogue, char* buf, size_t len) {
     if (!buf || len == 0) { set_error("conv_kernel_name: null buffer"); return RTOD_E_ARG; }
     int n = -1;
     if (variant >= 100 + PATCH_VARIANT_BASE) n = conv_patch_kernel_name(variant - 100 - PATCH_VARIANT_BASE, epilogue, buf, len);
+    else if (variant >= 100 + PWD_VARIANT_BASE) n = conv_pwd_kernel_name(variant - 100 - PWD_VARIANT_BASE, epilogue, buf, len);
     else if (variant >= 100 + RING_VARIANT_BASE) n = conv_ring_kernel_name(variant - 100 - RING_VARIANT_BASE, epilogue, buf, len);
     else if (variant >= 100 + BAND_VARIANT_BASE) n = conv_band_kernel_name(variant - 100 - BAND_VARIANT_BASE, epilogue, buf, len);
     else if (variant >= 100) n = conv_f16s3_kernel_name(variant - 100, epilogue, buf, len);

@@ -1,0 +1,184 @@
+// Pieces shared by the kernels that load their weight fragments straight from global memory (conv_bandd_f16s3.hip: 3x3 band;
+// conv_pwd_f16s3.hip: 1x1): counted vmcnt waits, the raw fragment load, register ties, and the epilogue in row passes.
+#pragma once
+#include "conv_f16s3_common.h"
+
+namespace rtod {
+
+template <int N> __device__ __forceinline__ void bandd_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 16, "vmcnt literal");
+#define RTOD_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(16)
+#undef RTOD_VMCNT_CASE
+}
+
+// wait for all but the NBASE + 2 n youngest operations, n (0 ... 5) wave-uniform: the band pieces issued after the awaited B set
+template <int NBASE> __device__ __forceinline__ void bandd_wait_vmcnt_plus(int n) {
+    static_assert(NBASE == 4 || NBASE == 8, "two B sets of 2 or 4 loads");
+    asm volatile("" : "+s"(n));                                 // opaque: left visible, the loop-invariant n unswitches the whole chunk loop six ways
+    if constexpr (NBASE == 8) {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    } else {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    }
+}
+
+// raw buffer load with an instruction offset (the 16-column tile of the strip: j KiB), hidden from the compiler's waitcnt pass
+template <int OFF> __device__ __forceinline__ u32x4 bandd_load_b(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voffset), "s"(rsrc), "s"(soffset), "n"(OFF) : "memory");
+    return v;
+}
+
+// hi and lo piece of one 16-row band block: lane l's 16 bytes land at lds + 16 l (M0 written in the statement that uses it)
+__device__ __forceinline__ void bandd_dma_pair(const __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soff_hi, unsigned soff_lo, unsigned lds_hi) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_add_u32 m0, %5, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(soff_hi), "s"(soff_lo), "s"(lds_hi)
+        : "memory", "scc");
+}
+
+template <int TN> __device__ __forceinline__ void bandd_tie(u32x4 (&q)[TN][2]) {
+    static_assert(TN >= 1 && TN <= 2, "strip width");
+    if constexpr (TN == 1) asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]) :: "memory");
+    else asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]) :: "memory");
+}
+
+// ---- epilogue: scale / bias / activation, LDS transpose in passes of RG rows, split-format store (+ residual).
+// Arithmetic and expression shapes are those of conv_f16s3_epilogue (conv_f16s3_common.h): the same bits.  Unlike that
+// function a pass may cover a PART of a wave's rows (a wave owns all BM rows of its strip; the whole tile would need 64 KB).
+template <int BM, int BN, int WM, int WN, int NT, int RG, bool RES, int KG>
+__device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[WM / 16][WN / 16], unsigned char* smem, int bm, int bn, int tid,
+                                               int wm, int wn, int lr, int lh, int M, int kg) {
+    constexpr int TM = WM / 16, TN = WN / 16, MT = 16, NE = 4, TS = BN;
+    static_assert(BM % RG == 0 && RG % 16 == 0, "epilogue pass");
+    float* T = reinterpret_cast<float*>(smem);
+    float amax = 0.f;
+    const float escale = SPLIT_SCALE;
+    constexpr int GPR = BN / 8;
+    constexpr int NG = (RG * GPR + NT - 1) / NT;
+    // every global load of the epilogue up front, for ALL passes: bias / scale of the wave's column tiles, then the residual
+    // operands (vmcnt retires in order: the transpose only has to wait for the first).  Loaded per pass, every pass paid the
+    // memory latency again, between two barriers.
+    constexpr int NP = BM / RG;
+    float bias_j[TN], inv_j[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn * BN + wn * WN + j * MT + lr;
+        const int nc = n < a.Cout ? n : 0;
+        const float b = a.bias[nc], iv = a.inv_scale[nc];
+        bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
+    }
+    f16x8 rq_h[RES ? NP : 1][RES ? NG : 1], rq_l[RES ? NP : 1][RES ? NG : 1];
+    if constexpr (RES) {
+        const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int g = tid + i * NT;
+                const int r = g / GPR, c8 = (g - r * GPR) * 8;
+                const int m = bm * BM + p * RG + r;
+                const bool ok = g < RG * GPR && m < M && bn * BN + c8 < a.Cout;
+                const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
+                const f16x8 th = *reinterpret_cast<const f16x8*>(q), tl = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
+                rq_h[p][i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                rq_l[p][i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+    }
+    __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
+#pragma unroll
+    for (int rg = 0; rg < BM; rg += RG) {
+        if constexpr (KG == 2) {                                         // K group 1 deposits its raw sums, group 0 adds its own
+            if (kg == 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r0 = wm * WM + i * MT;
+                    if (r0 >= rg && r0 < rg + RG) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) T[(r0 - rg + e + 4 * lh) * TS + wn * WN + j * MT + lr] = acc[i][j][e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (KG == 1 || kg == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WN + j * MT + lr;
+                const float bias = bias_j[j] * escale, inv = inv_j[j] * escale;
+                auto col = [&](auto act) {                                   // 0 linear, 1 leaky, 2 SiLU
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int r0 = wm * WM + i * MT;
+                        if (r0 >= rg && r0 < rg + RG) {                       // compile-time for one wave along M
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) {
+                                const int rl = r0 - rg + e + 4 * lh;
+                                float s = acc[i][j][e];
+                                if constexpr (KG == 2) s += T[rl * TS + nl];
+                                float v = s * inv + bias;
+                                if constexpr (decltype(act)::value == 2) v = silu_scaled(v, 1.0f / escale);
+                                else if constexpr (decltype(act)::value == 1) v = __builtin_fmaxf(v, v * 0.1f);
+                                T[rl * TS + nl] = v;
+                            }
+                        }
+                    }
+                };
+                if (a.leaky == 2) col(std::integral_constant<int, 2>{});
+                else if (a.leaky) col(std::integral_constant<int, 1>{});
+                else col(std::integral_constant<int, 0>{});
+            }
+        }
+        __syncthreads();
+        _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = tid + gi * NT;
+            if (g >= RG * GPR) continue;
+            const int r = g / GPR, c8 = (g - r * GPR) * 8;
+            const int m = bm * BM + rg + r;
+            if (m >= M || bn * BN + c8 >= a.Cout) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * TS + c8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if constexpr (RES) {
+                const f16x8 qh = rq_h[rg / RG][gi], ql = rq_l[rg / RG][gi];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)qh[e] + (float)ql[e];
+            }
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f16(v[e], h, l, amax); ph[e] = h; pl[e] = l; }
+            _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
+            store_act16(q, ph, false);
+            store_act16(q + a.out_ldc, pl, false);
+        }
+        if (rg + RG < BM) __syncthreads();
+    }
+    split_overflow_report(a.ovf, amax);
+}
+
+}  // namespace rtod

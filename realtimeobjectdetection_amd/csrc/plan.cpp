@@ -295,6 +295,7 @@ int Plan::set_option(const char* name, int value) {
     bool* flag = nullptr; int* num = nullptr;
     if (k == "fuse_pointwise") flag = &opt_fuse_pointwise;
     else if (k == "ring_kernel") flag = &opt_ring_kernel;
+    else if (k == "pwd_kernel") flag = &opt_pwd_kernel;
     else if (k == "stem2_kernel") flag = &opt_stem2_kernel;
     else if (k == "k_slices") flag = &opt_k_slices;
     else if (k == "bn_batch_stats") flag = &opt_bn_batch_stats;
@@ -803,6 +804,10 @@ int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStre
         if (pc.band) { set_error("patch variant requested for a band layer"); return RTOD_E_STATE; }
         return launch_conv_patch_f16s3(a, v - PATCH_VARIANT_BASE, s);
     }
+    if (v >= PWD_VARIANT_BASE) {
+        if (pc.band) { set_error("pointwise variant requested for a band layer"); return RTOD_E_STATE; }
+        return launch_conv_pwd_f16s3(a, v - PWD_VARIANT_BASE, s);
+    }
     if (v >= RING_VARIANT_BASE) {
         if (pc.band) { set_error("ring variant requested for a band layer"); return RTOD_E_STATE; }
         return launch_conv_ring_f16s3(a, v - RING_VARIANT_BASE, s);
@@ -872,7 +877,9 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
     const Launch& l = launches[li];
     const Layer& L = layers[l.layer];
     const bool pw = a.pw_wh != nullptr;
-    const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2, pw ? a.pw_cout : 0};
+    // shape + everything else the candidate set depends on (a second plan with other kernel-selection options must not inherit tiles)
+    const std::vector<int> key = {L.cin, L.cout, L.size, L.stride, L.hout, L.wout, l.in2_layer >= 0, l.out_layer == -2, pw ? a.pw_cout : 0,
+                                  convs[l.conv_slot].band ? 1 : 0, opt_ring_kernel ? 1 : 0, opt_patch_kernel ? 1 : 0, opt_pwd_kernel ? 1 : 0, L.act};
     auto it = tune_cache.find(key);
     if (it != tune_cache.end()) { tuning[li] = it->second; return RTOD_OK; }
     // process-wide memo (device, batch, shape): a second plan of the same network (bench.py keeps two batches in flight)
@@ -901,6 +908,12 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
                 if (conv_patch_mode_info(m).bn > L.cout && conv_patch_mode_info(m).bn > 64) continue;
                 if (!conv_patch_mode_valid(m, L.cin, L.cout)) continue;
                 cand.push_back(PATCH_VARIANT_BASE + m);
+            }
+        // (the slab tiles use the epilogue of the band family, which carries all three activations)
+        if (pwd_candidate(l, L))
+            for (int m = 0; m < PWD_MODES; ++m) {
+                if (conv_pwd_mode_info(m).bn > 128 && conv_pwd_mode_info(m).bn > (L.cout + 127) / 128 * 128) continue;   // tile wider than the layer
+                cand.push_back(PWD_VARIANT_BASE + m);
             }
         if (!pw && L.act <= 1 && opt_ring_kernel)
             for (int m = 0; m < RING_MODES; ++m) {
@@ -966,6 +979,7 @@ int Plan::set_tiles(int batch, const int* variants, int count) {
         if (band) ok = v >= BAND_VARIANT_BASE && v < BAND_VARIANT_BASE + BAND_MODES && conv_band_mode_valid(v - BAND_VARIANT_BASE, L.cin, L.hin, L.win);
         else if (v >= PATCH_VARIANT_BASE) ok = v < PATCH_VARIANT_BASE + PATCH_MODES && !hosts_pw && l.out_layer != -2 && L.act <= 1 && L.hout == L.hin &&
                                                conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, L.cin, L.cout);
+        else if (v >= PWD_VARIANT_BASE) ok = v < PWD_VARIANT_BASE + PWD_MODES && pwd_candidate(l, L);
         else if (v >= RING_VARIANT_BASE) ok = v < RING_VARIANT_BASE + RING_MODES && !hosts_pw && L.act <= 1;
         else ok = v < HV_COUNT && !(hosts_pw && conv_f16s3_variant_info(v).bn < L.cout);
         if (!ok) { set_error("set_tiles: variant %d is not a valid tile of launch %d (layer %d)", v, i, l.layer); return RTOD_E_ARG; }
@@ -980,7 +994,8 @@ int Plan::variant_for(const Launch& l, int batch) const {
         const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
-        if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active()) && FL.act <= 1) return v;
+        if (v >= PWD_VARIANT_BASE && v < PWD_VARIANT_BASE + PWD_MODES) { if (pwd_candidate(l, FL)) return v; }
+        else if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active()) && FL.act <= 1) return v;
         if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 && FL.act <= 1 &&
             conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, FL.cin, FL.cout)) return v;
         const int g = choose_variant_f16s3(layers[l.layer], batch);
@@ -998,6 +1013,12 @@ int Plan::variant_for(const Launch& l, int batch) const {
 }
 
 bool Plan::pw_active() const { return precision == 1 && opt_fuse_pointwise; }
+// plain 1x1 layer the slab tiles of conv_pwd_f16s3.hip can run: no fused head decode, no hosted pointwise conv, whole 64-channel slabs
+bool Plan::pwd_candidate(const Launch& l, const Layer& L) const {
+    if (!opt_pwd_kernel || l.conv_slot < 0 || convs[l.conv_slot].band || !convs[l.conv_slot].split) return false;
+    if (l.out_layer == -2 || (l.pw_guest >= 0 && pw_active())) return false;
+    return conv_pwd_supported(L.size, L.stride, L.pad, convs[l.conv_slot].cin_p) && L.hout == L.hin && L.wout == L.win;
+}
 bool Plan::stem2_active() const { return precision == 1 && opt_stem2_kernel && stem2_pattern && !keep_all && convs[launches[0].conv_slot].split; }
 
 int Plan::choose_variant_f16s3(const Layer& L, int batch) const {

@@ -103,6 +103,7 @@ struct Plan {
     bool opt_stem2_kernel = true;     // stem + layer 1 (+ hosted 1x1) in one kernel when the cfg starts like Darknet-53 (split-f16 plans)
     bool opt_patch_kernel = true;     // 2-D patch tiles among the autotune candidates of the wide 3x3 stride-1 layers
     bool opt_ring_kernel = true;      // persistent LDS-DMA ring tiles among the autotune candidates of the other layers
+    bool opt_pwd_kernel = true;       // slab tiles (conv_pwd_f16s3.hip) among the autotune candidates of the plain 1x1 layers
     bool opt_fuse_shortcut = true;    // shortcut in the producing conv's epilogue (else stand-alone add kernel)
     bool opt_fuse_decode = true;      // head decode in the head conv's epilogue (else stand-alone decode kernel)
     bool opt_zero_copy_concat = true; // route producers write straight into the concat buffer (else copy kernels)
@@ -134,7 +135,8 @@ struct Plan {
     int launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStream_t s) const;
     int variant_for(const Launch& l, int batch) const;
     int f32_slice_mode(const Launch& l, int batch, int variant) const;   // 0 plain, 1 slices inside the workgroup, 2 one workgroup per slice
-    bool pw_active() const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
+    bool pw_active() const;
+    bool pwd_candidate(const Launch& l, const Layer& L) const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
     bool stem2_pattern = false;                 // launches 0 / 1 are a stem and the stride-2 conv conv_stem2_f16s3 fuses (set by plan_buffers)
     bool stem2_active() const;                  // ... and the plan runs them fused (split-f16 precision, option stem2_kernel)
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)

@@ -158,6 +158,15 @@ constexpr int RING_VARIANT_BASE = 70;      // variant ids >= this: RING_VARIANT_
 const ConvVariantInfo& conv_ring_mode_info(int mode);
 int conv_ring_kernel_name(int mode, int epi, char* buf, size_t len);
 int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s);
+// 1x1 convolutions with the A operand staged in 64-channel slabs (full-line LDS-DMA) and weight fragments straight from global
+// memory (conv_pwd_f16s3.hip, round 4): same K order and MFMA sequence as the generic / ring tiles -> further autotune candidates
+// of the plain 1x1 layers (no fused decode, no hosted pointwise conv), bit-identical results.
+constexpr int PWD_MODES = 6;
+constexpr int PWD_VARIANT_BASE = 90;       // variant ids in [90, 110): PWD_VARIANT_BASE + mode
+bool conv_pwd_supported(int ksize, int stride, int pad, int cin);
+const ConvVariantInfo& conv_pwd_mode_info(int mode);
+int conv_pwd_kernel_name(int mode, int epi, char* buf, size_t len);
+int launch_conv_pwd_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 // Stem + first stride-2 convolution (+ hosted 1x1) in one persistent kernel (conv_stem2_f16s3.hip): the stem's output never
 // leaves the CU.  Bit-identical to the stand-alone kernels.
 constexpr int STEM2_VARIANT = 130;         // variant id reported for the fused launch
