@@ -87,6 +87,8 @@ def self_launch(args):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # this pool's host driver only supports dmabuf IPC: without it RCCL's (and torch's) cross-process device-memory handles
+        # fail with "hipIpcGetMemHandle: invalid argument".  The image exports it already; kept for a caller with a scrubbed environment.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         # rank 0 owns stdout (the one JSON line); the other ranks' stdout goes to stderr
@@ -354,6 +356,45 @@ def extra_workloads(dev, args):
     return out
 
 
+def as_run_bn_workload(dev, args):
+    """What the two-import-line drop-in of INTEGRATION.md section 1 runs when the caller, like the reference's detect.py:185-194,
+    never calls .eval(): BatchNorm on the statistics of the batch (src/darknet.py:493-495) — exact-fp32 kernels, raw conv ->
+    bn_stats -> bn_apply per layer, running statistics updated on the device (one launch) — through the reference's calling
+    sequence.  YOLOv3 at the headline resolution and batch; a slow parity path, reported so that its cost is a number."""
+    import warnings
+    import torch
+    from realtimeobjectdetection_amd import cfgs, synth
+    from realtimeobjectdetection_amd.cfg import parse_cfg_text, build_ir
+    from realtimeobjectdetection_amd.darknet import Darknet
+    from realtimeobjectdetection_amd.util import write_results
+    R, B = args.res, args.batch
+    text = cfgs.yolov3_cfg()
+    w = synth.synth_weights(build_ir(parse_cfg_text(text), R))
+    with tempfile.TemporaryDirectory() as d:
+        m = Darknet(cfgs.write_cfg(os.path.join(d, "yolov3.cfg"), text), True)      # no .eval(): as detect.py builds it
+        m.net_info["height"] = R
+        m.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, R)).to(dev)
+    steps, warm = max(1, min(args.steps, 10)), 2
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for _ in range(warm):
+            det = write_results(m(x), 80, args.conf, args.nms)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            det = write_results(m(x), 80, args.conf, args.nms)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"workload": "YOLOv3 cfg %dx%d batch=%d, Darknet(cfg, True) left in TRAINING mode (batch-statistics BatchNorm, what detect.py:185-194 runs), "
+                        "reference calling sequence y = model(x); write_results(y, 80, conf, nms)" % (R, R, B),
+            "value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warm,
+            "precision": m.active_precision, "launches_per_forward": int(m._info.n_launches),
+            "detections_last_step": 0 if isinstance(det, int) else int(det.size(0)),
+            "note": "parity path (exact-fp32 kernels; frames of a batch depend on each other; tolerance of this mode: DESIGN.md section 1); "
+                    "call .eval() for the headline path"}
+
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np  # noqa: F401
@@ -372,10 +413,10 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  RTOD_BENCH_BACKEND=gloo lets two ranks share one GPU for a dry run of this path.
         backend = os.environ.get("RTOD_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # (no device_id: the communicator is created lazily by the first collective on the device set above — the long-standing
+        #  path; barriers name the device explicitly)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    barrier_kw = {"device_ids": [dev.index]} if world > 1 and os.environ.get("RTOD_BENCH_BACKEND", "nccl") == "nccl" else {}
 
     from realtimeobjectdetection_amd import synth
     from realtimeobjectdetection_amd.shard import FixedGather
@@ -431,14 +472,14 @@ def run_rank(args):
         for _ in range(args.warmup):
             fn(nm)
         if world > 1:
-            dist.barrier()
+            dist.barrier(**barrier_kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = fn(nm)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(**barrier_kw)
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -514,6 +555,9 @@ def run_rank(args):
     if rank == 0 and world == 1 and not args.no_extras and R == 608 and B == 8:
         del extra, models[1:]                           # their arenas are not needed any more
         other = extra_workloads(dev, args)
+    as_run = None
+    if rank == 0 and world == 1 and not args.no_extras and R == 608 and B == 8:
+        as_run = as_run_bn_workload(dev, args)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg_text, w, R, B, args.conf, args.nms)
@@ -547,6 +591,8 @@ def run_rank(args):
             line["roofline"] = roof
         if other is not None:
             line["other_configs"] = other
+        if as_run is not None:
+            line["as_run_bn"] = as_run
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -3,6 +3,7 @@
 // decode, confidence mask, IoU.  All are HBM-bound elementwise work: one float4 (16 B) per lane
 // along the channel axis wherever the layout allows, grid capped at ~2048 blocks + grid stride.
 #include "rtod_internal.h"
+#include <algorithm>
 
 namespace rtod {
 
@@ -375,13 +376,124 @@ __global__ void bn_apply_kernel(View x, View y, View res, int has_res, int B, co
     }
 }
 
-int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act, hipStream_t s) {
+// Two-stage statistics (round 4): bn_stats_kernel above reads 16 bytes per pixel row from C/4 workgroups (8 for the first layer) —
+// every line of the tensor fetched for one of its eight 16-byte pieces at a time.  Here the pixels are cut into `nparts` ranges, a
+// workgroup reads its range with consecutive threads on consecutive channels (whole lines), reduces its 256 / (C/4) pixel lanes
+// through LDS in a fixed tree and writes per-channel partial sums; bn_stats_final_kernel adds the parts in ascending order.
+// Fixed partition, fixed order: deterministic.  Needs 256 % (C/4) == 0 or (C/4) % 256 == 0; other channel counts keep the old kernel.
+constexpr int BN_PARTS_MAX = 1024;
+__global__ __launch_bounds__(256)
+void bn_stats_partial_kernel(View x, int B, double* __restrict__ partial, int pstride, int nparts) {
+    const int C4 = x.C / 4;
+    const int64_t npix = (int64_t)B * x.H * x.W;
+    const int64_t per = (npix + nparts - 1) / nparts;
+    const int64_t p0 = blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    __shared__ double red[2][4][256];
+    for (int cb = 0; cb < C4; cb += 256) {
+        const int W = C4 - cb < 256 ? C4 - cb : 256;            // channel quads handled in this pass (divides 256)
+        const int PL = 256 / W;                                 // pixel lanes
+        const int cq = cb + (int)threadIdx.x % W, pl = (int)threadIdx.x / W;
+        double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+        for (int64_t p = p0 + pl; p < p1; p += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x.base + x.coff + cq * 4 + p * x.ldc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; q[e] += (double)v[e] * (double)v[e]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] = s[e]; red[1][e][threadIdx.x] = q[e]; }
+        __syncthreads();
+        for (int w = PL / 2; w > 0; w >>= 1) {                  // lanes pl and pl + w of the same channel quad
+            if (pl < w) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] += red[0][e][threadIdx.x + w * W]; red[1][e][threadIdx.x] += red[1][e][threadIdx.x + w * W]; }
+            }
+            __syncthreads();
+        }
+        if (pl == 0) {
+            double* o = partial + (int64_t)blockIdx.x * 2 * pstride;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[cq * 4 + e] = red[0][e][threadIdx.x]; o[pstride + cq * 4 + e] = red[1][e][threadIdx.x]; }
+        }
+    }
+}
+
+// 16 channels per workgroup, 16 lanes per channel: lane k adds parts k, k + 16, ... in ascending order, then a fixed tree over the lanes
+// (one thread per channel walking all parts was a chain of `nparts` dependent L2 round trips: 29 us per layer)
+__global__ __launch_bounds__(256)
+void bn_stats_final_kernel(const double* __restrict__ partial, int pstride, int nparts, int C, double npix, double* __restrict__ stats, int sstride,
+                           const float* __restrict__ bn, int gstride, float* __restrict__ wb) {
+    const int cl = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0, q = 0;
+    if (c < C)
+        for (int k = k0; k < nparts; k += 16) { s += partial[(int64_t)k * 2 * pstride + c]; q += partial[(int64_t)k * 2 * pstride + pstride + c]; }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (k0 < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w * 16]; red[1][threadIdx.x] += red[1][threadIdx.x + w * 16]; }
+        __syncthreads();
+    }
+    if (k0 != 0 || c >= C) return;
+    s = red[0][threadIdx.x]; q = red[1][threadIdx.x];
+    const double mean = s / npix;
+    double var = q / npix - mean * mean;
+    if (var < 0) var = 0;
+    stats[c] = mean;
+    stats[sstride + c] = var;
+    // the normalisation's per-channel constants, once per channel instead of once per element (same expressions as bn_apply_kernel)
+    const double invstd = 1.0 / sqrt(var + 1e-5);
+    wb[c] = (float)(invstd * (double)bn[gstride + c]);
+    wb[sstride + c] = (float)((double)bn[c] - mean * invstd * (double)bn[gstride + c]);
+}
+
+// y = x * w + b, activation, + shortcut with the per-channel constants of bn_stats_final_kernel
+__global__ void bn_apply_wb_kernel(View x, View y, View res, int has_res, int B, const float* __restrict__ wb, int sstride, int act) {
+    const int C4 = x.C / 4;
+    const int64_t total = (int64_t)B * x.H * x.W * C4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        const int64_t p = t / C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x.base + x.coff + c + p * x.ldc);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wb + c), b = *reinterpret_cast<const f32x4*>(wb + sstride + c);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (has_res) r = *reinterpret_cast<const f32x4*>(res.base + res.coff + c + p * res.ldc);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = v[e] * w[e] + b[e];
+            u = apply_act(u, act);
+            o[e] = has_res ? u + r[e] : u;
+        }
+        *reinterpret_cast<f32x4*>(y.base + y.coff + c + p * y.ldc) = o;
+    }
+}
+
+size_t bn_partial_doubles(int max_channels) { return (size_t)BN_PARTS_MAX * 2 * (size_t)max_channels + (size_t)max_channels; }   // partial sums + [2][C] float constants
+
+int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act,
+                    double* partial, int64_t partial_doubles, hipStream_t s) {
     if (x.split || y.split || (res && res->split)) { set_error("bn_batch: exact-fp32 plans only"); return RTOD_E_ARG; }
     if (!view_ok4(x) || !view_ok4(y) || x.C != y.C || x.H != y.H || x.W != y.W || !stats || !bn || gstride < x.C || sstride < x.C) { set_error("bn_batch: bad views"); return RTOD_E_ARG; }
     if (res && (!view_ok4(*res) || res->C != x.C || res->H != x.H || res->W != x.W)) { set_error("bn_batch: bad shortcut view"); return RTOD_E_ARG; }
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(x.C / 4), dim3(256), 0, s, x, B, stats, sstride);
-    if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_stats launch");
-    const int64_t total = (int64_t)B * x.H * x.W * (x.C / 4);
+    const int C4 = x.C / 4;
+    const int64_t npix = (int64_t)B * x.H * x.W;
+    int nparts = (int)std::min<int64_t>(BN_PARTS_MAX, std::max<int64_t>(1, npix / 128));
+    if (partial && (256 % C4 == 0 || C4 % 256 == 0) && (int64_t)nparts * 2 * sstride + sstride <= partial_doubles) {
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nparts), dim3(256), 0, s, x, B, partial, sstride, nparts);
+        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_stats_partial launch");
+        float* wb = reinterpret_cast<float*>(partial + (int64_t)nparts * 2 * sstride);
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((x.C + 15) / 16), dim3(256), 0, s, partial, sstride, nparts, x.C, (double)npix, stats, sstride, bn, gstride, wb);
+        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_stats_final launch");
+        View r = res ? *res : x;
+        hipLaunchKernelGGL(bn_apply_wb_kernel, dim3(grid_for(npix * C4, 256)), dim3(256), 0, s, x, y, r, res ? 1 : 0, B, wb, sstride, act);
+        return hip_fail(hipGetLastError(), "bn_apply launch");
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(x.C / 4), dim3(256), 0, s, x, B, stats, sstride);
+        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "bn_stats launch");
+    }
+    const int64_t total = npix * C4;
     View r = res ? *res : x;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, y, r, res ? 1 : 0, B, stats, sstride, bn, gstride, act);
     return hip_fail(hipGetLastError(), "bn_apply launch");

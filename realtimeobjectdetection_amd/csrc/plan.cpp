@@ -44,6 +44,7 @@ Plan::~Plan() {
     if (d_arena) (void)hipFree(d_arena);
     if (d_scratch) (void)hipFree(d_scratch);
     if (d_bn_stats) (void)hipFree(d_bn_stats);
+    if (d_bn_partial) (void)hipFree(d_bn_partial);
     if (d_weights) (void)hipFree(d_weights);
 }
 
@@ -761,6 +762,10 @@ int Plan::load_weights(const float* w, size_t n) {
     if (opt_bn_batch_stats && !d_bn_stats && bn_stats_doubles > 0) {
         RTOD_HIP(hipMalloc((void**)&d_bn_stats, sizeof(double) * (size_t)bn_stats_doubles));
         RTOD_HIP(hipMemset(d_bn_stats, 0, sizeof(double) * (size_t)bn_stats_doubles));
+        int maxn = 0;
+        for (const auto& pc : convs) if (pc.stats_off >= 0) maxn = std::max(maxn, pc.Npad);
+        bn_partial_count = (int64_t)bn_partial_doubles(maxn);
+        RTOD_HIP(hipMalloc((void**)&d_bn_partial, sizeof(double) * (size_t)bn_partial_count));
     }
     if (!d_scratch) {
         bool any = false;
@@ -1072,7 +1077,7 @@ int Plan::forward(const float* x, int batch, float* out, hipStream_t s, float* l
                         if (rc) return rc;
                         const View o = view_of(l.out_layer);
                         View r; if (l.in2_layer >= 0) r = view_of(l.in2_layer);
-                        rc = launch_bn_batch(o, o, l.in2_layer >= 0 ? &r : nullptr, batch, d_bn_stats + pc.stats_off, pc.Npad, d_weights + pc.bn_off, pc.Npad, L.act, s);
+                        rc = launch_bn_batch(o, o, l.in2_layer >= 0 ? &r : nullptr, batch, d_bn_stats + pc.stats_off, pc.Npad, d_weights + pc.bn_off, pc.Npad, L.act, d_bn_partial, bn_partial_count, s);
                     } else
                     rc = launch_conv(a, v, s);
                 }

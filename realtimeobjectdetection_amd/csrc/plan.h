@@ -86,6 +86,8 @@ struct Plan {
     float* d_weights = nullptr;
     double* d_bn_stats = nullptr;     // batch-statistics BatchNorm: per-channel mean / biased variance of every BN layer's last forward
     int64_t bn_stats_doubles = 0;
+    double* d_bn_partial = nullptr;   // per-range partial sums of the two-stage statistics kernel
+    int64_t bn_partial_count = 0;
     float* d_scratch = nullptr;       // exact-fp32 plans: slice panels of the one-workgroup-per-K-slice schedule
     int64_t scratch_floats = 0;
     bool weights_loaded = false;

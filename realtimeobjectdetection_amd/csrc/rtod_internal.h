@@ -196,7 +196,9 @@ int launch_add(const View& a, const View& b, const View& out, int B, hipStream_t
 int launch_maxpool(const View& in, const View& out, int B, int size, int stride, int pad, hipStream_t s);   // pad > 0: symmetric -inf padding
 int launch_upsample_nearest2x(const View& in, const View& out, int B, hipStream_t s);
 // batch-statistics BatchNorm (+ activation + shortcut) over a conv's raw output, in place (aux_kernels.hip); stats: 2*C doubles of scratch
-int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act, hipStream_t s);
+int launch_bn_batch(const View& x, const View& y, const View* res, int B, double* stats, int sstride, const float* bn, int gstride, int act,
+                    double* partial, int64_t partial_doubles, hipStream_t s);    // partial: scratch of the two-stage statistics (bn_partial_doubles), or null
+size_t bn_partial_doubles(int max_channels);
 // running_mean / running_var update of every BatchNorm layer of a batch-statistics plan in one launch (aux_kernels.hip)
 struct BnUpdateEntry { float* running_mean; float* running_var; int64_t stats_off; double unbias; int sstride; int channels; };
 constexpr int BN_UPDATE_MAX = 32;                 // entries per launch (by-value kernel argument: 32 x 40 bytes)

@@ -27,3 +27,26 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- two-rank job of tests/test_shard_gpu.py: started HERE, at the end of collection, because this process has not made a GPU
+# call yet (an exec from a process that has initialised the GPU is refused on the pool); the test only waits for its result.
+_SHARD_JOB = {"job": None}
+
+
+def pytest_collection_finish(session):
+    if not any(item.name == "test_two_ranks_on_device_tensors" for item in session.items):
+        return
+    if not os.path.exists("/dev/kfd"):                          # no GPU driver here (build container): the test skips
+        return
+    import subprocess
+    import tempfile
+    out = tempfile.mkdtemp(prefix="rtod_shard_gpu_")
+    log = open(os.path.join(out, "job.log"), "w")
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_gpu_job.py"), out], stdout=log, stderr=subprocess.STDOUT)
+    _SHARD_JOB["job"] = {"out": out, "proc": proc}
+
+
+@pytest.fixture(scope="session")
+def shard_gpu_job():
+    return _SHARD_JOB["job"]
