@@ -589,6 +589,7 @@ static int launch_band(const ConvArgs& a, hipStream_t s) {
 int conv_band_layer_kg(int cin, int h, int w) { return (cin % 64 == 0 && cin >= 512 && h * w <= 400) ? 2 : 1; }
 bool conv_band_mode_valid(int mode, int cin, int h, int w) {
     if (mode < 0 || mode >= BAND_MODES) return false;
+    if (mode == BANDD_WIDE_MODE) return false;                     // the wide tile belongs to the non-band layers (94 < W <= 160)
     if (mode >= BAND_LDS_MODES) return conv_bandd_mode_kg(mode - BAND_LDS_MODES) == conv_band_layer_kg(cin, h, w);
     return (mode >= BAND_K2_MODE0 ? 2 : 1) == conv_band_layer_kg(cin, h, w);
 }

@@ -45,7 +45,8 @@
 
 namespace rtod {
 
-constexpr int BANDD_MAX_W = 94;
+constexpr int BANDD_MAX_W = 94;           // tiles of the band layers (conv_band_supported)
+constexpr int BANDD_WIDE_W = 160;         // the wide tile: 3x3 layers with 94 < W <= 160 (152x152 at 608, 104x104 at 416), one band buffer of up to 29 blocks
 
 // Diagnostic build only (make timeline -> librtod_tl.so, -DRTOD_TIMELINE): per workgroup (wave 0) wall clock at start / end and shader
 // cycles spent in: prologue, chunk tops (arrival -> barrier passed), chunk bodies, drain, epilogue.  The product library compiles none of it.
@@ -61,7 +62,7 @@ __host__ __device__ constexpr int bandd_rows(int bm, int w) { return (bm + 2 * w
 // BM x BN workgroup tile; NWM x NWN waves per K group, each wave a (BM/NWM) x (BN/NWN) strip (NWM = 1: no weight byte is
 // loaded twice in a workgroup).  DB: double-buffered band.  KG = 2: two wave groups on the even / odd channel chunks (own band
 // buffers), summed in the epilogue — the split-K layers of conv_band_f16s3.hip (conv_band_layer_kg), same summation order.
-template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, int BUFM, int KG>
+template <int BM, int BN, int NWM, int NWN, int MINW, int EPI, int BUFM, int KG, int MAXW>
 __global__ __launch_bounds__(NWM * NWN * 64 * KG, MINW)
 void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
     // BUFM: 0 one band buffer, replaced between two barriers at every chunk top (the load is exposed; other workgroups cover it);
@@ -77,7 +78,7 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     static_assert(TN <= 2, "strip width: 16 or 32 columns (instruction offsets, tie)");
     constexpr int NB = 2 * TN;                                  // B loads of one step
     constexpr int UNITS = 9 * TM;                               // (tap, 16-row tile) units of one channel chunk
-    constexpr int NBLK_MAX = bandd_rows(BM, BANDD_MAX_W) / 16;
+    constexpr int NBLK_MAX = bandd_rows(BM, MAXW) / 16;
     constexpr int PPW = (NBLK_MAX + NW - 1) / NW;               // band blocks per wave, at most
     constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;   // epilogue rows per pass (<= 32 KB of fp32)
 
@@ -128,7 +129,7 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     // Every wave issues the SAME number of pieces, n_dma = ceil(NBLK / NW) pairs (the counted waits of the steps behind a DMA
     // need it): a wave whose block index runs past the band writes zeros (out-of-range source) into the zero block instead.
     const int n_dma = (NBLK + NW - 1) / NW;
-    static_assert(PPW <= 5, "bandd_wait_vmcnt_plus covers 5 pairs");
+    static_assert(PPW <= 5 || !DB, "bandd_wait_vmcnt_plus covers 5 pairs");
     // blocks [blk_lo, blk_hi) of channel chunk cc -> band buffer buf, n pairs per wave (n = ceil((blk_hi - blk_lo) / NW), wave-uniform)
     auto dma_blocks = [&](int cc, int buf, int blk_lo, int blk_hi, int n) __attribute__((always_inline)) {
         const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
@@ -308,7 +309,7 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
 #endif
 }
 
-template <int BM, int BN, int NWM, int NWN, int MINW, int BUFM, int KG>
+template <int BM, int BN, int NWM, int NWN, int MINW, int BUFM, int KG, int MAXW>
 static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     constexpr bool DB = BUFM == 1;
     constexpr int NT = NWM * NWN * 64 * KG;
@@ -322,13 +323,13 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     const int epi_bytes = RG * BN * 4;
     const int lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     if (lds > 160 * 1024) { set_error("launch_conv_bandd: %d bytes of LDS", lds); return RTOD_E_ARG; }
-    auto k_res = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, BUFM, KG>;
-    auto k_plain = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, BUFM, KG>;
+    auto k_res = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT_RES, BUFM, KG, MAXW>;
+    auto k_plain = conv_bandd_f16s3_kernel<BM, BN, NWM, NWN, MINW, EPI_SPLIT, BUFM, KG, MAXW>;
     static std::atomic<unsigned long long> attr_done{0};       // per instantiation, one bit per device; > 64 KiB of dynamic LDS needs the opt-in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "conv_bandd_f16s3 hipGetDevice");
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        const int cap = KG * (DB ? 2 : 1) * (bandd_rows(BM, BANDD_MAX_W) / 16 + 1) * 2048;
+        const int cap = KG * (DB ? 2 : 1) * (bandd_rows(BM, MAXW) / 16 + 1) * 2048;
         const int mx = std::min(cap > epi_bytes ? cap : epi_bytes, 160 * 1024);    // (a launch that needs more is refused above)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_res), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
@@ -385,26 +386,30 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
 }
 
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
-//   X(index, BM, BN, waves along M, waves along N, MINW, double-buffered band, K groups, name suffix)
+//   X(index, BM, BN, waves along M, waves along N, MINW, double-buffered band, K groups, widest image, name suffix)
 #define RTOD_BANDD_TILES(X) \
-    X(0, 128, 128, 1, 4, 3, 0, 1, "") X(1, 128, 128, 1, 4, 3, 1, 1, ",db") X(2, 64, 128, 1, 4, 4, 1, 1, ",db") \
-    X(3, 64, 128, 1, 4, 4, 1, 2, ",db,k2") X(4, 128, 128, 1, 4, 2, 1, 2, ",db,k2") \
-    X(5, 96, 128, 1, 4, 3, 1, 1, ",db") X(6, 96, 128, 1, 4, 3, 1, 2, ",db,k2")
+    X(0, 128, 128, 1, 4, 3, 0, 1, 94, "") X(1, 128, 128, 1, 4, 3, 1, 1, 94, ",db") X(2, 64, 128, 1, 4, 4, 1, 1, 94, ",db") \
+    X(3, 64, 128, 1, 4, 4, 1, 2, 94, ",db,k2") X(4, 128, 128, 1, 4, 2, 1, 2, 94, ",db,k2") \
+    X(5, 96, 128, 1, 4, 3, 1, 1, 94, ",db") X(6, 96, 128, 1, 4, 3, 1, 2, 94, ",db,k2") \
+    X(7, 128, 128, 1, 4, 2, 0, 1, 160, ",w160")
 // (measured and dropped: 128x64 tiles of 128x16 strips, double-buffered, with and without split-K — 3-9 % behind the 32-column strips on every grid)
 
-#define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
+#define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, maxw, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},
 static const ConvVariantInfo kBanddModes[BANDD_MODES] = { RTOD_BANDD_TILES(RTOD_X_INFO) };
 #undef RTOD_X_INFO
 const ConvVariantInfo& conv_bandd_mode_info(int idx) { return kBanddModes[idx < 0 || idx >= BANDD_MODES ? 0 : idx]; }
+bool conv_bandd_wide_supported(int ksize, int stride, int pad, int cin, int w_in) {
+    return ksize == 3 && stride == 1 && pad == 1 && cin % 32 == 0 && w_in > BANDD_MAX_W && w_in <= BANDD_WIDE_W;
+}
 int conv_bandd_mode_kg(int idx) {
-#define RTOD_X_KG(i, bm, bn, nwm, nwn, minw, db, kg, sfx) if (idx == i) return kg;
+#define RTOD_X_KG(i, bm, bn, nwm, nwn, minw, db, kg, maxw, sfx) if (idx == i) return kg;
     RTOD_BANDD_TILES(RTOD_X_KG)
 #undef RTOD_X_KG
     return 0;
 }
 int conv_bandd_kernel_name(int idx, int epi, char* buf, size_t len) {
-#define RTOD_X_NAME(i, bm, bn, nwm, nwn, minw, db, kg, sfx) \
-    if (idx == i) return snprintf(buf, len, "void rtod::conv_bandd_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #db ", " #kg ">(rtod::ConvArgs, int, int)", epi);
+#define RTOD_X_NAME(i, bm, bn, nwm, nwn, minw, db, kg, maxw, sfx) \
+    if (idx == i) return snprintf(buf, len, "void rtod::conv_bandd_f16s3_kernel<" #bm ", " #bn ", " #nwm ", " #nwn ", " #minw ", %d, " #db ", " #kg ", " #maxw ">(rtod::ConvArgs, int, int)", epi);
     RTOD_BANDD_TILES(RTOD_X_NAME)
 #undef RTOD_X_NAME
     return -1;
@@ -412,18 +417,18 @@ int conv_bandd_kernel_name(int idx, int epi, char* buf, size_t len) {
 
 int launch_conv_bandd_f16s3(const ConvArgs& a, int idx, hipStream_t s) {
     if (!a.in || !a.w_hi || !a.w_lo || !a.bias || !a.inv_scale || !a.out) { set_error("launch_conv_bandd: null pointer"); return RTOD_E_ARG; }
-    if (!conv_band_supported(a.kh, a.stride, a.pad, a.Cin, a.Wi) || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled || a.pw_wh) {
+    if (a.kh != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 32 || a.Wi > BANDD_WIDE_W || a.kw != 3 || a.Ho != a.Hi || a.Wo != a.Wi || a.dec.enabled || a.pw_wh) {
         set_error("launch_conv_bandd: unsupported shape (k=%d s=%d pad=%d Cin=%d W=%d)", a.kh, a.stride, a.pad, a.Cin, a.Wi); return RTOD_E_ARG;
     }
     if (a.in_ldc % 8 || a.in_coff % 8 || a.K != a.Kpad || a.K != 9 * a.Cin || a.Npad % 128) { set_error("launch_conv_bandd: bad view / K"); return RTOD_E_ARG; }
     if (a.in_bytes == 0 || a.in_bytes >= OOB || a.w_bytes == 0 || a.w_bytes >= OOB) { set_error("launch_conv_bandd: buffer extents"); return RTOD_E_ARG; }
     if ((uint64_t)a.B * a.Hi * a.Wi * a.in_ldc * 4ull > (uint64_t)a.in_bytes) { set_error("launch_conv_bandd: input view exceeds its buffer"); return RTOD_E_ARG; }
     switch (idx) {
-#define RTOD_X_CASE(i, bm, bn, nwm, nwn, minw, db, kg, sfx) case i: return launch_bandd<bm, bn, nwm, nwn, minw, db, kg>(a, s);
+#define RTOD_X_CASE(i, bm, bn, nwm, nwn, minw, db, kg, maxw, sfx) case i: if (a.Wi > maxw) break; return launch_bandd<bm, bn, nwm, nwn, minw, db, kg, maxw>(a, s);
         RTOD_BANDD_TILES(RTOD_X_CASE)
 #undef RTOD_X_CASE
     }
-    set_error("launch_conv_bandd: mode %d unsupported", idx);
+    set_error("launch_conv_bandd: mode %d unsupported (image width %d)", idx, a.Wi);
     return RTOD_E_ARG;
 }
 

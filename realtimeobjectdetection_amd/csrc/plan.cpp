@@ -818,6 +818,7 @@ int Plan::launch_split_variant(ConvArgs& a, const PackedConv& pc, int v, hipStre
         return launch_conv_ring_f16s3(a, v - RING_VARIANT_BASE, s);
     }
     if (v >= BAND_VARIANT_BASE) {
+        if (v == BAND_VARIANT_BASE + BANDD_WIDE_MODE && !pc.band) return launch_conv_bandd_f16s3(a, v - BAND_VARIANT_BASE - BAND_LDS_MODES, s);
         if (!pc.band) { set_error("band variant requested for a layer without band weights"); return RTOD_E_STATE; }
         return launch_conv_band_f16s3(a, v - BAND_VARIANT_BASE, s);
     }
@@ -915,6 +916,7 @@ int Plan::tune_launch(size_t li, ConvArgs& a, int batch, hipStream_t s) {
                 cand.push_back(PATCH_VARIANT_BASE + m);
             }
         // (the slab tiles use the epilogue of the band family, which carries all three activations)
+        if (bandd_wide_candidate(l, L)) cand.push_back(BAND_VARIANT_BASE + BANDD_WIDE_MODE);
         if (pwd_candidate(l, L))
             for (int m = 0; m < PWD_MODES; ++m) {
                 if (conv_pwd_mode_info(m).bn > 128 && conv_pwd_mode_info(m).bn > (L.cout + 127) / 128 * 128) continue;   // tile wider than the layer
@@ -985,6 +987,7 @@ int Plan::set_tiles(int batch, const int* variants, int count) {
         else if (v >= PATCH_VARIANT_BASE) ok = v < PATCH_VARIANT_BASE + PATCH_MODES && !hosts_pw && l.out_layer != -2 && L.act <= 1 && L.hout == L.hin &&
                                                conv_patch_supported(L.size, L.stride, L.pad, L.cin, L.cout) && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, L.cin, L.cout);
         else if (v >= PWD_VARIANT_BASE) ok = v < PWD_VARIANT_BASE + PWD_MODES && pwd_candidate(l, L);
+        else if (v == BAND_VARIANT_BASE + BANDD_WIDE_MODE) ok = bandd_wide_candidate(l, L);
         else if (v >= RING_VARIANT_BASE) ok = v < RING_VARIANT_BASE + RING_MODES && !hosts_pw && L.act <= 1;
         else ok = v < HV_COUNT && !(hosts_pw && conv_f16s3_variant_info(v).bn < L.cout);
         if (!ok) { set_error("set_tiles: variant %d is not a valid tile of launch %d (layer %d)", v, i, l.layer); return RTOD_E_ARG; }
@@ -999,7 +1002,8 @@ int Plan::variant_for(const Launch& l, int batch) const {
         const int v = opt_force_f16s3_variant;
         const Layer& FL = layers[l.layer];
         if (band) return conv_band_mode_valid(v - BAND_VARIANT_BASE, FL.cin, FL.hin, FL.win) ? v : BAND_VARIANT_BASE + conv_band_default_mode(FL.cin, FL.hin, FL.win);
-        if (v >= PWD_VARIANT_BASE && v < PWD_VARIANT_BASE + PWD_MODES) { if (pwd_candidate(l, FL)) return v; }
+        if (v == BAND_VARIANT_BASE + BANDD_WIDE_MODE) { if (bandd_wide_candidate(l, FL)) return v; }
+        else if (v >= PWD_VARIANT_BASE && v < PWD_VARIANT_BASE + PWD_MODES) { if (pwd_candidate(l, FL)) return v; }
         else if (v >= RING_VARIANT_BASE && v < RING_VARIANT_BASE + RING_MODES && !(l.pw_guest >= 0 && pw_active()) && FL.act <= 1) return v;
         if (v >= PATCH_VARIANT_BASE && v < PATCH_VARIANT_BASE + PATCH_MODES && !(l.pw_guest >= 0 && pw_active()) && l.out_layer != -2 && FL.act <= 1 &&
             conv_patch_supported(FL.size, FL.stride, FL.pad, FL.cin, FL.cout) && FL.hout == FL.hin && conv_patch_mode_valid(v - PATCH_VARIANT_BASE, FL.cin, FL.cout)) return v;
@@ -1018,6 +1022,13 @@ int Plan::variant_for(const Launch& l, int batch) const {
 }
 
 bool Plan::pw_active() const { return precision == 1 && opt_fuse_pointwise; }
+// 3x3 stride-1 layer too wide for the band family's LDS budget at three workgroups per CU but not for its one-buffer tile
+bool Plan::bandd_wide_candidate(const Launch& l, const Layer& L) const {
+    if (!opt_band_kernel || l.conv_slot < 0 || convs[l.conv_slot].band || !convs[l.conv_slot].split) return false;
+    if (l.out_layer == -2 || (l.pw_guest >= 0 && pw_active())) return false;
+    const PackedConv& pc = convs[l.conv_slot];
+    return conv_bandd_wide_supported(L.size, L.stride, L.pad, pc.cin_p, L.win) && L.hout == L.hin && L.wout == L.win && pc.Npad % 128 == 0 && pc.K == pc.Kpad;
+}
 // plain 1x1 layer the slab tiles of conv_pwd_f16s3.hip can run: no fused head decode, no hosted pointwise conv, whole 64-channel slabs
 bool Plan::pwd_candidate(const Launch& l, const Layer& L) const {
     if (!opt_pwd_kernel || l.conv_slot < 0 || convs[l.conv_slot].band || !convs[l.conv_slot].split) return false;

@@ -138,7 +138,8 @@ struct Plan {
     int variant_for(const Launch& l, int batch) const;
     int f32_slice_mode(const Launch& l, int batch, int variant) const;   // 0 plain, 1 slices inside the workgroup, 2 one workgroup per slice
     bool pw_active() const;
-    bool pwd_candidate(const Launch& l, const Layer& L) const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
+    bool pwd_candidate(const Launch& l, const Layer& L) const;
+    bool bandd_wide_candidate(const Launch& l, const Layer& L) const;                     // fused pointwise convs in use (precision 1, option fuse_pointwise)
     bool stem2_pattern = false;                 // launches 0 / 1 are a stem and the stride-2 conv conv_stem2_f16s3 fuses (set by plan_buffers)
     bool stem2_active() const;                  // ... and the plan runs them fused (split-f16 precision, option stem2_kernel)
     std::map<int, std::vector<int>> tuned;     // batch -> per-launch split-f16 tile variant (-1: heuristic)

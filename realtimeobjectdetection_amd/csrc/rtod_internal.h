@@ -134,7 +134,7 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 // A layer the band kernel supports ALWAYS runs on it (its split-K layers sum in a different order than the generic kernel, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
-constexpr int BANDD_MODES = 7;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
+constexpr int BANDD_MODES = 8;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
 constexpr int BAND_LDS_MODES = 11;         // conv_band_f16s3.hip: 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
                                            // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2, 64x128/2x4, 128x64/4x2 (13x13 grids)
 constexpr int BAND_MODES = BAND_LDS_MODES + BANDD_MODES;
@@ -142,6 +142,10 @@ static_assert(50 + BAND_MODES <= 70, "band variant ids end where the ring kernel
 constexpr int BAND_K2_MODE0 = 7;
 const ConvVariantInfo& conv_bandd_mode_info(int idx);
 int conv_bandd_mode_kg(int idx);
+// the last bandd tile (one band buffer of up to 29 blocks, two workgroups per CU) also runs 3x3 stride-1 layers with 94 < W <= 160: same K
+// order and MFMA sequence as the generic tiles, so it is one more autotune candidate of those (non-band) layers
+constexpr int BANDD_WIDE_MODE = BAND_LDS_MODES + 7;       // band-family mode index -> variant BAND_VARIANT_BASE + BANDD_WIDE_MODE
+bool conv_bandd_wide_supported(int ksize, int stride, int pad, int cin, int w_in);
 int conv_bandd_kernel_name(int idx, int epi, char* buf, size_t len);
 int launch_conv_bandd_f16s3(const ConvArgs& a, int idx, hipStream_t s);
 int conv_band_layer_kg(int cin, int h, int w);
