@@ -75,14 +75,8 @@ constexpr int TL_BLOCKS = 2048;
 __device__ unsigned long long g_band_tl[TL_BLOCKS * 4];
 #endif
 
-// Timing-only ablation of the main loop (never in a shipped library; outputs are garbage): -DRTOD_ABL=<bits>  1 no epilogue,
-// 2 no global loads (32: no band loads only, 64: no weight loads only), 4 no LDS writes, 8 fragments read once, 16 no barrier inside the loop,
-// 128 (with 2 / 64) keep wait_b's scheduling fences.  Used with -DRTOD_TIMELINE, whose
-// per-workgroup cycle counts separate cycles from the clock the chip holds.
-#ifndef RTOD_ABL
-#define RTOD_ABL 0
-#endif
-
+// (Round 3's timing-only ablation knobs of this main loop — RTOD_ABL: no epilogue / no loads / no LDS writes / fragments read once /
+//  no barrier — are kept as profiles/experiments/r03_band_ablation_knobs.patch: apply it, then `make abl ABL=<bits>`.)
 
 constexpr int BAND_MAX_W = 94;
 // Epilogue flavour.  0 (default): pixel-major accumulators, LDS-transposed stores (256-byte runs per pixel).  1: transposed
@@ -211,9 +205,6 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 
     int ld_step = 0, ld_cc = 0, ld_tap = 0;                    // B chunk to be loaded next: local step, its chunk and tap
     auto gload_b = [&](BStage& S) {
-#if RTOD_ABL & (2 | 64)
-        return;
-#endif
         const bool live = ld_step < nsteps;
         const unsigned koff = (unsigned)((ld_cc * KG + kg) * 9 + ld_tap) * wchunk;
 #pragma unroll
@@ -226,9 +217,6 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         if (++ld_tap == 9) { ld_tap = 0; ++ld_cc; }
     };
     auto gload_band = [&](int cc) {
-#if RTOD_ABL & (2 | 32)
-        return;
-#endif
         const bool live = cc < n_cc;
         const unsigned soff = (unsigned)(cc * KG + kg) * 64u;
 #pragma unroll
@@ -247,36 +235,18 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     // loads cost, 14-21 % of these kernels in the timing-only builds of tools/run_abl.sh, is throughput, not latency.)
     int band_age = 0;                                          // steps since the last band prefetch was issued
     auto wait_b = [&](BStage& S) {
-#if RTOD_ABL & (2 | 64)
-#if RTOD_ABL & 128
-        tie_regs(S.bh); tie_regs(S.bl);                        // timing experiment: no loads, the scheduling fences kept
-        ++band_age;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        return;
-#endif
         if (band_age < 2) wait_vmcnt<B_LOADS + BAND_LOADS>(); else wait_vmcnt<B_LOADS>();
         tie_regs(S.bh); tie_regs(S.bl);
         ++band_age;
         __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_band = [&]() {                                   // everything issued so far except the two B sets
-#if RTOD_ABL & (2 | 32)
-        return;
-#endif
-#if RTOD_ABL & 64
-        wait_vmcnt<0>();
-#else
         wait_vmcnt<2 * B_LOADS>();
-#endif
         tie_regs(BRh); tie_regs(BRl);
         __builtin_amdgcn_sched_barrier(0);
     };
     const int wr_swz = (c16 ^ band_swz(row0)) << 4;            // RPP % 8 == 0: the same for every pass
     auto write_b = [&](const BStage& S, int buf) {
-#if RTOD_ABL & 4
-        return;
-#endif
         unsigned char* st = bst + buf * BSTAGE;
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
@@ -288,9 +258,6 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
     };
     auto write_band = [&]() {
-#if RTOD_ABL & 4
-        return;
-#endif
 #pragma unroll
         for (int j = 0; j < BAND_SLOTS; ++j) {
             const int o = (row0 + j * RPP) * 64 + wr_swz;
@@ -327,18 +294,10 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         }
     };
     // per 16-column group: two B fragments, then 3 TM products (lo*hi, hi*lo, hi*hi: small terms first)
-#if RTOD_ABL & 8
-    f16x8 bh[TN], bl[TN];
-    bool abl_have = false;
-#endif
     auto compute = [&](int buf) {
         const unsigned char* st = bst + buf * BSTAGE + b_lane;
-#if !(RTOD_ABL & 8)
         f16x8 bh[TN], bl[TN];
-#else
-        if (!abl_have)
-#endif
-#if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
+#if RTOD_BFRAG_AHEAD
         // B fragments LA = 2 column groups ahead of their products: a read is covered by the 3 TM MFMAs of the group before it
         // (left to itself the scheduler reads each pair just in time — 8 registers of fragments, a wait in front of every MFMA
         // pair).  A/B on one box, 76x76 / 38x38 layers: -3.3 % / -2.0 %; LA = 1: as before; LA = 3 or all four groups up front
@@ -373,7 +332,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             }
-#if RTOD_BFRAG_AHEAD && !(RTOD_ABL & 8)
+#if RTOD_BFRAG_AHEAD
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
             if (j + LA < TN) { read_bj(j + LA); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
 #endif
@@ -409,9 +368,6 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
     // one step = one (channel chunk, tap): compute chunk t from B buffer t&1, stage chunk t+1, load chunk t+3.
     // After the last tap of a channel chunk the band is replaced (all waves have read it: the step's barrier).
     auto step = [&](int buf, BStage& Snext) {
-#if RTOD_ABL & 8
-        if (!abl_have)
-#endif
 #ifdef RTOD_STAMPS
         const int age_ = band_age;
 #endif
@@ -427,13 +383,8 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
         __builtin_amdgcn_sched_barrier(0);
         RTOD_STAMP(2)                                          // 2: B LDS writes + next loads issued
         compute(buf);
-#if RTOD_ABL & 8
-        abl_have = true;
-#endif
         RTOD_STAMP(3)                                          // 3: B reads + MFMA issue
-#if !(RTOD_ABL & 16)
         __syncthreads();
-#endif
         RTOD_STAMP(4)                                          // 4: barrier
         if (++tap == 9) {
             tap = 0; ++cc;
@@ -442,9 +393,7 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
                 write_band();
                 gload_band(cc + 1);
                 band_age = 0;
-#if !(RTOD_ABL & 16)
                 __syncthreads();
-#endif
                 RTOD_STAMP(5)                                  // 5: band replacement
             }
         }
@@ -464,17 +413,12 @@ void conv_band_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n
 #ifdef RTOD_DIAG
     if (a.dbg & 4) return;
 #endif
-#if RTOD_ABL
-    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));      // keep the accumulators (and the MFMAs) alive
-#endif
-#if !(RTOD_ABL & 1)
     if constexpr (BAND_TR) {
         int mrow[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) { const int m = bm * BM + wm * WM + i * 16 + lr; mrow[i] = m < M ? m : -1; }
         conv_f16s3_epilogue_regs<WM, WN, EPI == EPI_SPLIT_RES, KG>(a, acc, smem, mrow, bn * BN + wn * WN, tid, lh, kg);
     } else conv_f16s3_epilogue<BM, BN, WM, WN, NT * KG, EPI, band_epi_bytes(BM, BN), KG>(a, acc, smem, bm, bn, (int)threadIdx.x, wm, wn, lr, lh, M, kg);
-#endif
 #ifdef RTOD_STAMPS
     RTOD_STAMP(7)                                              // 7: epilogue
     if ((threadIdx.x & 63) == 0 && blockIdx.x < STAMP_BLOCKS && (threadIdx.x >> 6) < STAMP_WAVES) {
