@@ -65,8 +65,10 @@ __global__ __launch_bounds__(NW * 64, MINW)
 void conv_pwd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n) {
     constexpr int BN = NW * 32, NT = NW * 64, TM = BM / 16, TN = 2;
     constexpr int SLAB = BM * 256;                              // bytes of one slab: BM rows x 64 channels x (hi + lo)
-    constexpr int NPP = BM / 8 / NW;                            // 8-row groups (hi + lo DMA pairs) per wave and slab
-    static_assert(BM % 16 == 0 && (BM / 8) % NW == 0 && NPP >= 1 && NPP <= 4, "slab pieces per wave");
+    constexpr int NP = BM / 8;                                  // 8-row groups (hi + lo DMA pairs) of a slab
+    constexpr int NPP = (NP + NW - 1) / NW;                     // ... per wave: every wave issues the same number (counted waits); a group past
+                                                                // the slab has an out-of-range source and lands in a 4 KiB dump behind the ring
+    static_assert(BM % 16 == 0 && NPP >= 1 && NPP <= 4, "slab pieces per wave");
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;   // epilogue rows per pass (<= 32 KB of fp32)
     constexpr int WAIT_B = 8 + 2 * NPP;                         // younger than the awaited B set: one B set, one slab, one B set
@@ -102,7 +104,7 @@ void conv_pwd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n)
         const int p = wave + k * NW;
         const int r = lane >> 3;
         const int m = m0 + p * 8 + r;
-        dma_vo[k] = m < M ? (unsigned)m * PS + (unsigned)(a.in_coff + (((lane & 7) ^ r) << 3)) * 2u : OOB;
+        dma_vo[k] = (p < NP && m < M) ? (unsigned)m * PS + (unsigned)(a.in_coff + (((lane & 7) ^ r) << 3)) * 2u : OOB;
     }
     auto dma_slab = [&](int js) __attribute__((always_inline)) {
         const bool live = js < NS;
@@ -111,7 +113,8 @@ void conv_pwd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n)
 #pragma unroll
         for (int k = 0; k < NPP; ++k) {
             const int p = wave + k * NW;
-            pwd_dma_pair(rs_a, live ? dma_vo[k] : OOB, soff, lo_plane + soff, base + (unsigned)((p >> 1) * 4096 + (p & 1) * 1024));
+            pwd_dma_pair(rs_a, live ? dma_vo[k] : OOB, soff, lo_plane + soff,
+                         p < NP ? base + (unsigned)((p >> 1) * 4096 + (p & 1) * 1024) : lds0 + (unsigned)(NST * SLAB));
         }
     };
     // ---- B fragments: lane (lr, lh) <- weight row n0 + 16 j + lr, 16-byte chunk lh of the step's panel; four register sets (t % 4)
@@ -212,7 +215,7 @@ static int launch_pwd(const ConvArgs& a, hipStream_t s) {
     const int gm = (M + BM - 1) / BM, gn = (a.Cout + BN - 1) / BN;
     ConvArgs ax = a;
     ax.xcd_by_n = (gn % 8 == 0 && (int64_t)a.Cout * a.K > (int64_t)M * a.Cin) ? 1 : 0;
-    constexpr int ring_bytes = NST * BM * 256, epi_bytes = RG * BN * 4;
+    constexpr int ring_bytes = NST * BM * 256 + ((BM / 8) % NW ? 4096 : 0), epi_bytes = RG * BN * 4;
     constexpr int lds = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS");
     auto k_res = conv_pwd_f16s3_kernel<BM, NW, NST, MINW, EPI_SPLIT_RES>;
@@ -236,7 +239,7 @@ static int launch_pwd(const ConvArgs& a, hipStream_t s) {
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
 //   X(index, BM, waves (BN = 32 waves), ring slabs, MINW)
 #define RTOD_PWD_TILES(X) \
-    X(0, 64, 4, 3, 3) X(1, 32, 4, 3, 3) X(2, 128, 4, 3, 1) X(3, 64, 8, 3, 1) X(4, 64, 4, 2, 3) X(5, 32, 4, 4, 3)
+    X(0, 64, 4, 3, 3) X(1, 32, 4, 3, 3) X(2, 128, 4, 3, 1) X(3, 64, 8, 3, 1) X(4, 64, 4, 2, 3) X(5, 32, 4, 4, 3) X(6, 96, 4, 2, 3) X(7, 96, 4, 3, 2) X(8, 48, 4, 3, 3) X(9, 48, 4, 4, 3)
 
 #define RTOD_X_INFO(idx, bm, nw, nst, minw) {bm, nw * 32, "conv_pwd_f16s3<" #bm "x" #nw "w,r" #nst ">"},
 static const ConvVariantInfo kPwdModes[PWD_MODES] = { RTOD_PWD_TILES(RTOD_X_INFO) };

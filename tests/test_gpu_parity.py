@@ -383,7 +383,7 @@ def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path
     depends on the batch (which is why eval mode is the canonical, shardable path).
 
     TOLERANCE OF THIS MODE (stated in DESIGN.md section 1 and INTEGRATION.md section 1): 99.9 % of the output within the
-    path's 1e-4, maximum within 5e-4.  Evidence, profiles/r03_trainbn_floor.json (tools/trainbn_floor.py, CPU only): the
+    path's 1e-4, maximum within 3.5e-4 (2.5x the reference's own float32-vs-float64 distance in this mode; measured 2.1-2.7e-4).  Evidence, profiles/r03_trainbn_floor.json (tools/trainbn_floor.py, CPU only): the
     reference's own float32 evaluation of this mode sits 1.4-1.5e-4 (max) from the float64 evaluation of the same graph —
     16x its eval-mode distance (9e-6) — and moves by 4e-5 when only its thread count changes; normalising by the statistics
     of 300-340 samples per channel on the 13x13 / 10x10 grids amplifies the convolutions' rounding layer by layer
@@ -407,7 +407,8 @@ def test_training_mode_batch_statistics_vs_reference_golden(golden_dir, tmp_path
     stride = int(g["stride_" + tag])
     got = y.cpu().numpy()[:, ::stride]
     e = rel_err(got, g["rows_" + tag])
-    assert np.quantile(e, 0.999) <= TOL and e.max() <= 5e-4, (float(np.quantile(e, 0.999)), float(e.max()))
+    print("as-run BatchNorm %s: p99.9 %.2e, max %.2e (gate 1e-4 / 3.5e-4)" % (tag, float(np.quantile(e, 0.999)), float(e.max())))
+    assert np.quantile(e, 0.999) <= TOL and e.max() <= 3.5e-4, "p99.9 %.3e max %.3e" % (float(np.quantile(e, 0.999)), float(e.max()))
     # side effect on the module buffers (momentum 0.1, unbiased variance), first and last BatchNorm layer
     bns = [(i, mod) for i, seq in enumerate(m.module_list) for mod in seq.children() if isinstance(mod, torch.nn.BatchNorm2d)]
     for i, bn in (bns[0], bns[-1]):
@@ -883,7 +884,7 @@ def test_forward_is_capturable_after_autotune(tmp_path_factory):
 def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     """Autotune may pick any tile of a kernel family for a layer, per batch size: every candidate must produce the same
     bits (same K order, same MFMA shape).  Forces each split-f16 tile variant in turn (generic implicit-GEMM tiles 0-11
-    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-67 on the band layers (61-67: conv_bandd_f16s3.hip, weight fragments straight from global memory; 68: its wide tile on the 3x3 layers with 94 < W <= 160), slab tiles 90-95 on the
+    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-67 on the band layers (61-67: conv_bandd_f16s3.hip, weight fragments straight from global memory; 68: its wide tile on the 3x3 layers with 94 < W <= 160), slab tiles 90-99 on the
     plain 1x1 layers (conv_pwd_f16s3.hip), 2-D patch tiles 110-114 on the wide 3x3 layers) — this also launches every instantiation, including the ones autotune rarely picks."""
     from realtimeobjectdetection_amd.darknet import Darknet
     res = 416
@@ -893,7 +894,7 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
     x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
     ref = None
-    for v in list(range(12)) + list(range(50, 69)) + list(range(70, 78)) + list(range(90, 96)) + list(range(110, 115)):
+    for v in list(range(12)) + list(range(50, 69)) + list(range(70, 78)) + list(range(90, 100)) + list(range(110, 115)):
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
         m.precision = "f16s3"
