@@ -90,21 +90,30 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
         bias_j[j] = n < a.Cout ? b : 0.f; inv_j[j] = n < a.Cout ? iv : 0.f;
     }
     f16x8 rq_h[RES ? NP : 1][RES ? NG : 1], rq_l[RES ? NP : 1][RES ? NG : 1];
+    // Item (pass p, i) of a thread is row p RG + tid / GPR + i (NT / GPR), 8 channels at (tid % GPR) 8 when NT is a multiple of GPR
+    // (every tile of this family): row and channel split ONCE, addresses advance by a constant — the per-item 64-bit multiplies of
+    // `m * 2 * ldc` (quarter-rate v_mul_lo_u32) were ~5 % of the epilogue's vector time.
+    static_assert(NT % GPR == 0, "epilogue items: constant row step");
+    constexpr int RSTEP = NT / GPR;
+    const int er = tid / GPR, ec8 = (tid - er * GPR) * 8;
+    const bool ecol = bn * BN + ec8 < a.Cout;
     if constexpr (RES) {
         const _Float16* rh0 = reinterpret_cast<const _Float16*>(a.res) + a.res_coff + bn * BN;
+        const int64_t rstep = (int64_t)RSTEP * 2 * a.res_ldc;
+        const _Float16* const q0 = rh0 + (int64_t)(bm * BM + er) * 2 * a.res_ldc + ec8;
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < NP; ++p) {
+            const _Float16* q = q0 + (int64_t)(p * RG) * 2 * a.res_ldc;
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
-                const int g = tid + i * NT;
-                const int r = g / GPR, c8 = (g - r * GPR) * 8;
-                const int m = bm * BM + p * RG + r;
-                const bool ok = g < RG * GPR && m < M && bn * BN + c8 < a.Cout;
-                const _Float16* q = rh0 + (int64_t)(ok ? m : 0) * 2 * a.res_ldc + (ok ? c8 : 0);
-                const f16x8 th = *reinterpret_cast<const f16x8*>(q), tl = *reinterpret_cast<const f16x8*>(q + a.res_ldc);
-                rq_h[p][i] = ok ? th : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                rq_l[p][i] = ok ? tl : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                const int m = bm * BM + p * RG + er + i * RSTEP;
+                // rows past M / channels past Cout are never stored: their operand only has to come from a valid address
+                const _Float16* qq = (er + i * RSTEP < RG && m < M && ecol) ? q : rh0;      // (a pass's last item may be partial: RG GPR items over NT threads)
+                rq_h[p][i] = *reinterpret_cast<const f16x8*>(qq);
+                rq_l[p][i] = *reinterpret_cast<const f16x8*>(qq + a.res_ldc);
+                q += rstep;
             }
+        }
     }
     __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
 #pragma unroll
@@ -153,16 +162,15 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
             }
         }
         __syncthreads();
-        _Float16* oh = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN;
+        _Float16* oq = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN + (int64_t)(bm * BM + rg + er) * 2 * a.out_ldc + ec8;
+        const int64_t ostep = (int64_t)RSTEP * 2 * a.out_ldc;
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            const int g = tid + gi * NT;
-            if (g >= RG * GPR) continue;
-            const int r = g / GPR, c8 = (g - r * GPR) * 8;
+        for (int gi = 0; gi < NG; ++gi, oq += ostep) {
+            const int r = er + gi * RSTEP;
             const int m = bm * BM + rg + r;
-            if (m >= M || bn * BN + c8 >= a.Cout) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * TS + c8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + c8 + 4);
+            if (r >= RG || m >= M || !ecol) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * TS + ec8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * TS + ec8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if constexpr (RES) {
                 const f16x8 qh = rq_h[rg / RG][gi], ql = rq_l[rg / RG][gi];
@@ -172,9 +180,8 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
             f16x8 ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f16(v[e], h, l, amax); ph[e] = h; pl[e] = l; }
-            _Float16* q = oh + (int64_t)m * 2 * a.out_ldc + c8;
-            store_act16(q, ph, false);
-            store_act16(q + a.out_ldc, pl, false);
+            store_act16(oq, ph, false);
+            store_act16(oq + a.out_ldc, pl, false);
         }
         if (rg + RG < BM) __syncthreads();
     }

@@ -113,6 +113,10 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     const unsigned PS = (unsigned)a.in_ldc * 4u;
     const unsigned lo_plane = (unsigned)a.in_ldc * 2u;
 
+    // (Round 4 also measured per-GROUP chunk-top barriers for the KG == 2 tiles — an arrival counter in LDS per K group instead of the
+    //  workgroup's s_barrier, so that one group's wait would be the other's MFMA time: bit-identical, 1.5 % SLOWER on the 19x19 layers in
+    //  an in-process A/B (profiles/experiments/r04_epilogue_groupbarrier_ab.log).  The 39 k cycles a wave spends at the chunk tops of a
+    //  19x19 tile are mostly its SIMD partner's MFMA time: inside the loop the pipe is already ~80 % busy.)
     // zero blocks (hi row 0 and lo row 0 of the block behind the band), every buffer of every group
     if (threadIdx.x < 8 * (DB ? 2 : 1) * KG) {
         const int b = threadIdx.x >> 3, k = threadIdx.x & 7;
