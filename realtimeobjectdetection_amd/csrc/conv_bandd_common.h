@@ -5,12 +5,32 @@
 
 namespace rtod {
 
+#ifdef RTOD_TIMELINE
+// diagnostic build: shader cycles of the epilogue's phases per workgroup (thread 0): [0] loads issued + first barrier, [1] transpose writes,
+// [2] barrier, [3] tile reads + shortcut + split + stores, [4] trailing barrier
+constexpr int BD_EPI_BLOCKS = 2048;
+static __device__ unsigned long long g_bandd_epi[BD_EPI_BLOCKS * 5];
+#define BD_ESTAMP(slot) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); et_[slot] += tn_ - eprev_; eprev_ = tn_; }
+#else
+#define BD_ESTAMP(slot)
+#endif
+
 template <int N> __device__ __forceinline__ void bandd_wait_vmcnt() {
     static_assert(N >= 0 && N <= 16, "vmcnt literal");
 #define RTOD_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(16)
+    RTOD_VMCNT_CASE(2) RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(5) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(9) RTOD_VMCNT_CASE(10) RTOD_VMCNT_CASE(12) RTOD_VMCNT_CASE(16)
 #undef RTOD_VMCNT_CASE
+}
+
+// the same with a count that is a constant only after unrolling (a loop variable of a fully unrolled loop): the switch folds
+__device__ __forceinline__ void bandd_wait_vmcnt_folded(int n) {
+    switch (n) {
+#define RTOD_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        RTOD_VMCNT_CASE(4) RTOD_VMCNT_CASE(5) RTOD_VMCNT_CASE(6) RTOD_VMCNT_CASE(8) RTOD_VMCNT_CASE(9) RTOD_VMCNT_CASE(10)
+#undef RTOD_VMCNT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;          // (never taken: stricter, still correct)
+    }
 }
 
 // wait for all but the NBASE + 2 n youngest operations, n (0 ... 5) wave-uniform: the band pieces issued after the awaited B set
@@ -72,6 +92,10 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
                                                int wm, int wn, int lr, int lh, int M, int kg) {
     constexpr int TM = WM / 16, TN = WN / 16, MT = 16, NE = 4, TS = BN;
     static_assert(BM % RG == 0 && RG % 16 == 0, "epilogue pass");
+#ifdef RTOD_TIMELINE
+    unsigned long long et_[5] = {0, 0, 0, 0, 0};
+    unsigned long long eprev_ = __builtin_amdgcn_s_memtime();
+#endif
     float* T = reinterpret_cast<float*>(smem);
     float amax = 0.f;
     const float escale = SPLIT_SCALE;
@@ -116,6 +140,7 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
         }
     }
     __syncthreads();                                            // every wave has read its last fragments: the band becomes the transpose tile
+    BD_ESTAMP(0)
 #pragma unroll
     for (int rg = 0; rg < BM; rg += RG) {
         if constexpr (KG == 2) {                                         // K group 1 deposits its raw sums, group 0 adds its own
@@ -161,7 +186,9 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
                 else col(std::integral_constant<int, 0>{});
             }
         }
+        BD_ESTAMP(1)
         __syncthreads();
+        BD_ESTAMP(2)
         _Float16* oq = reinterpret_cast<_Float16*>(a.out) + a.out_coff + bn * BN + (int64_t)(bm * BM + rg + er) * 2 * a.out_ldc + ec8;
         const int64_t ostep = (int64_t)RSTEP * 2 * a.out_ldc;
 #pragma unroll
@@ -183,8 +210,13 @@ __device__ __forceinline__ void bandd_epilogue(const ConvArgs& a, f32x4 (&acc)[W
             store_act16(oq, ph, false);
             store_act16(oq + a.out_ldc, pl, false);
         }
+        BD_ESTAMP(3)
         if (rg + RG < BM) __syncthreads();
+        BD_ESTAMP(4)
     }
+#ifdef RTOD_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < BD_EPI_BLOCKS) for (int i = 0; i < 5; ++i) g_bandd_epi[blockIdx.x * 5 + i] = et_[i];
+#endif
     split_overflow_report(a.ovf, amax);
 }
 

@@ -240,6 +240,10 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
     }
     __syncthreads();                                            // zero blocks written
 
+    // (Round 4 measured a prefetch of the tile's shortcut operand into L2 here — two dword touches per thread at steps 3 and 5 of the last
+    //  channel chunk, counted into the waits of steps 3-7: bit-identical, no gain (band76 +0.4 %, band38 -0.3 %, band19 +0.5 %).  The
+    //  epilogue's cost is vector issue — three waves per SIMD in the same phase — not the shortcut's latency: stamps and a timing
+    //  ablation in profiles/experiments/r04_bandd_epilogue_*.log, patch r04_bandd_shortcut_prefetch.patch.)
     BD_STAMP(0)
     __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
@@ -359,6 +363,14 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
                     if (st > smax) smax = st; if (en < emin) emin = en;
                 }
                 const double cyc = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+                double ep[5] = {0, 0, 0, 0, 0};
+                {
+                    static unsigned long long he[BD_EPI_BLOCKS * 5];
+                    const int ne = nb < BD_EPI_BLOCKS ? nb : BD_EPI_BLOCKS;
+                    if (hipMemcpyFromSymbol(he, HIP_SYMBOL(g_bandd_epi), sizeof(unsigned long long) * 5 * ne) == hipSuccess)
+                        for (int b = 0; b < ne; ++b) for (int i = 0; i < 5; ++i) ep[i] += (double)he[b * 5 + i] / ne / 1e3;
+                }
+                fprintf(stderr, "[timeline]   epilogue kcycles/wg (thread 0): loads + first barrier %.1f, transpose writes %.1f, barrier %.1f, reads + shortcut + split + stores %.1f, trailing barrier %.1f\n", ep[0], ep[1], ep[2], ep[3], ep[4]);
                 fprintf(stderr, "[timeline] bandd<%d,%d,%dx%d,db%d,k%d> W=%d Cin=%d Cout=%d res=%d wgs=%d lds=%d | span %.1f us | wg mean %.1f us, last start %.1f, first end %.1f | kcycles/wg: prologue %.1f tops %.1f bodies %.1f drain %.1f epilogue %.1f | clock %.0f MHz\n",
                         BM, BN, NWM, NWN, BUFM, KG, a.Wi, a.Cin, a.Cout, a.res ? 1 : 0, gm * gn, lds, (t1 - t0) / 100.0, rt / nb / 100.0, smax, emin,
                         ph[0] / nb / 1e3, ph[1] / nb / 1e3, ph[2] / nb / 1e3, ph[3] / nb / 1e3, ph[4] / nb / 1e3, rt > 0 ? cyc / rt * 100.0 : 0.0);
