@@ -407,7 +407,7 @@ static int launch_bandd(const ConvArgs& a, hipStream_t s) {
     X(0, 128, 128, 1, 4, 3, 0, 1, 94, "") X(1, 128, 128, 1, 4, 3, 1, 1, 94, ",db") X(2, 64, 128, 1, 4, 4, 1, 1, 94, ",db") \
     X(3, 64, 128, 1, 4, 4, 1, 2, 94, ",db,k2") X(4, 128, 128, 1, 4, 2, 1, 2, 94, ",db,k2") \
     X(5, 96, 128, 1, 4, 3, 1, 1, 94, ",db") X(6, 96, 128, 1, 4, 3, 1, 2, 94, ",db,k2") \
-    X(7, 128, 128, 1, 4, 2, 0, 1, 160, ",w160")
+    X(7, 128, 128, 1, 4, 2, 0, 1, 160, ",w160") X(8, 48, 128, 1, 4, 3, 1, 2, 94, ",db,k2")
 // (measured and dropped: 128x64 tiles of 128x16 strips, double-buffered, with and without split-K — 3-9 % behind the 32-column strips on every grid)
 
 #define RTOD_X_INFO(idx, bm, bn, nwm, nwn, minw, db, kg, maxw, sfx) {bm, bn, "conv_bandd_f16s3<" #bm "x" #bn "," #nwm "x" #nwn sfx ">"},

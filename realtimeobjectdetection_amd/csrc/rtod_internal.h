@@ -134,7 +134,7 @@ int launch_conv_f16s3(const ConvArgs& a, int variant, hipStream_t s);
 bool conv_band_supported(int ksize, int stride, int pad, int cin, int w_in);
 // A layer the band kernel supports ALWAYS runs on it (its split-K layers sum in a different order than the generic kernel, and
 // a frame's output must not depend on the batch it rides in); autotune only picks the tile.
-constexpr int BANDD_MODES = 8;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
+constexpr int BANDD_MODES = 9;             // conv_bandd_f16s3.hip (round 4): weight fragments straight from global memory, band by LDS-DMA
 constexpr int BAND_LDS_MODES = 11;         // conv_band_f16s3.hip: 128x128/4x2 waves, 128x64/4x2, 192x128/4x2, 192x128/6x2, 96x128/2x4, 128x128/2x2, 64x128/2x4,
                                            // and with in-workgroup split-K (two wave groups): 96x128/2x4, 128x128/4x2, 64x128/2x4, 128x64/4x2 (13x13 grids)
 constexpr int BAND_MODES = BAND_LDS_MODES + BANDD_MODES;
