@@ -195,8 +195,13 @@ void conv_bandd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_
             }
             vmw[i / 3] |= vm << ((i % 3) * 9);
             m += 16; ox += 16;
-            while (ox >= W) { ox -= W; ++oy; }
-            while (oy >= H) { oy -= H; ++b; }
+            if (W >= 16) {                                      // (uniform) one wrap at most: two selects instead of two divergent loops per tile
+                const bool wx = ox >= W; ox = wx ? ox - W : ox; oy += wx ? 1 : 0;
+                const bool wy = oy >= H; oy = wy ? oy - H : oy;
+            } else {
+                while (ox >= W) { ox -= W; ++oy; }
+                while (oy >= H) { oy -= H; ++b; }
+            }
         }
     }
 
