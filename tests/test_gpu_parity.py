@@ -460,6 +460,47 @@ def test_yolov5s_style_graph_vs_torch_ops(tmp_path_factory, res, B, precision):
     assert np.array_equal(dg, dw)
 
 
+def test_round4_tile_families_on_the_v5s_style_graph(tmp_path_factory):
+    """The round-4 tiles beyond YOLOv3's shapes: the slab tiles of the 1x1 layers (conv_pwd_f16s3.hip, variants 90-99) and the
+    bandd tiles (61-69) forced in turn on the YOLOv5s-shaped graph at 320x320 batch 3 — SiLU epilogues, 1x1 layers with 64 ... 512
+    input channels reading four-way concat buffers, 3x3 layers with fused shortcuts on 40 / 20 / 10-pixel grids (M tails on every
+    tile height: 3 * 100 pixels), heads with decode=v5 (which keep their generic tiles).  Every forced plan must give the bits of the
+    autotuned one and meet the oracle's PyTorch CPU ops at the path's tolerance."""
+    from realtimeobjectdetection_amd.darknet import Darknet
+    res, B = 320, 3
+    cfg_text = cfgs.yolov5s_style_cfg()
+    d = tmp_path_factory.mktemp("v5s_tiles")
+    cfg_path = cfgs.write_cfg(str(d / "v5s.cfg"), cfg_text)
+    ref = O.RefDarknet(cfg_text, res)
+    w = synth.synth_weights(ref.ir)
+    ref.load_weight_stream(w)
+    x = torch.from_numpy(synth.synth_frames(B, res, seed=52))
+    with torch.no_grad():
+        want = ref.forward(x)
+    base = None
+    used = set()
+    for v in [-1, 90, 91, 92, 93, 94, 96, 98, 61, 63, 66, 69]:
+        m = Darknet(cfg_path, True).eval()
+        m.net_info["height"] = res
+        m.precision = "f16s3"
+        m.autotune = v < 0
+        if v >= 0:
+            m.options["force_f16s3_variant"] = v
+        m.load_weight_stream(w)
+        with torch.no_grad():
+            y = m(x.cuda())
+        torch.cuda.synchronize()
+        assert m.active_precision == "f16s3" and not m.overflowed()
+        used |= {li.variant - 100 for li in m.launch_infos() if li.kind == 0}
+        if base is None:
+            base = y.clone()
+            assert rel_err(y.cpu().numpy(), want.numpy()).max() <= TOL
+        else:
+            assert torch.equal(y, base), v
+        del m
+    assert {90, 94, 96, 98} <= used and used & {61, 63, 66, 69}, sorted(used)      # the forced tiles really ran
+
+
 # ------------------------------------------------------------------------------- class-offset batched NMS (YOLOv5-style)
 def _v5_predictions(seed, B, n, C, clusters, spread, obj_lo=0.0):
     """Boxes drawn around a few cluster centres (so that suppression really happens), independent objectness / class scores."""
