@@ -52,7 +52,9 @@ constexpr int S2_IR = S2_PR + 2, S2_IC = S2_PC + 2;                     // 11 x 
 constexpr int S2_IN = 3 * S2_IR * S2_IC;                               // 1155 input values
 constexpr int S2_VPT = (S2_IN + 1 + S2_HT - 1) / S2_HT;                // input values per thread of a half (5)
 constexpr int S2_INP = S2_VPT * S2_HT;                                 // padded: dwords S2_IN.. stay zero (operand of the k >= 27 lanes)
-constexpr int S2_LDS = 2 * 2 * S2_PLANE + 2 * S2_W1 + 2 * S2_INP * 4 + (64 + 64 + 32 + 32) * 4;
+constexpr int S2_TAB = (64 + 64 + 32 + 32) * 4;
+constexpr int S2_ZERO = ((S2_PR - 1) * S2_IC + S2_PC - 1) * 4 + 4;         // zero region: reads at (receptive-field corner) + (zero-lane offset) for every corner
+constexpr int S2_LDS = 2 * 2 * S2_PLANE + 2 * S2_W1 + 2 * S2_INP * 4 + S2_TAB + (S2_ZERO + 15) / 16 * 16;
 static_assert(S2_INP >= S2_IN + 1, "input patch padding");
 static_assert(S2_TH == S2_HW, "one output row per wave of a half");
 
@@ -104,6 +106,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
     unsigned char* const w1 = smem + 2 * 2 * S2_PLANE;                  // [hi | lo][9][64][64], shared by both halves
     unsigned* const inp = reinterpret_cast<unsigned*>(w1 + 2 * S2_W1) + half * S2_INP;   // this half's [3][11][35] (hi | lo << 16) of 8*x, zero tail
     float* const tab = reinterpret_cast<float*>(w1 + 2 * S2_W1 + 2 * S2_INP * 4);        // inv1*8 [64], bias1*8 [64], inv2*8 [32], bias2*8 [32]
+    unsigned char* const zreg = w1 + 2 * S2_W1 + 2 * S2_INP * 4 + S2_TAB;                 // S2_ZERO bytes of zeros (operand of the k >= 27 lanes)
     const ConvArgs& c = a.c1;
     const int H = a.H, W = a.W;
     const int64_t plane = (int64_t)H * W;
@@ -127,6 +130,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
         for (int i = tid; i < 64; i += S2_NT) { tab[i] = c.inv_scale[i] * SPLIT_SCALE; tab[64 + i] = c.bias[i] * SPLIT_SCALE; }
         if constexpr (PW)
             for (int i = tid; i < 32; i += S2_NT) { tab[128 + i] = c.pw_inv_scale[i] * SPLIT_SCALE; tab[160 + i] = c.pw_bias[i] * SPLIT_SCALE; }
+        for (int i = tid; i < (S2_ZERO + 3) / 4; i += S2_NT) reinterpret_cast<unsigned*>(zreg)[i] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -157,14 +161,15 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             }
     }
     // input-patch dword of this lane's 8 k values (k = 8*lh + e = (ky*3 + kx)*3 + c) relative to the stem pixel's patch
-    // position; the k >= 27 lanes read the zero tail
+    // position; for the k >= 27 lanes the offset points from this half's input patch into the zero region, so that corner + offset
+    // reads a zero for every corner WITHOUT a per-value select (round 4: 8 selects per 16 pixels less)
     int koff[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = lh * 8 + e;
         const int tap = k / 3, cc = k - tap * 3;
         const int ky = tap / 3, kx = tap - ky * 3;
-        koff[e] = k < 27 ? ((cc * S2_IR + ky) * S2_IC + kx) * 4 : -1;
+        koff[e] = k < 27 ? ((cc * S2_IR + ky) * S2_IC + kx) * 4 : (int)(zreg - reinterpret_cast<unsigned char*>(inp));
     }
     // patch pixels of this lane's groups: group g = wq + 4 j, patch row q = 16*g + lr = py*33 + column slot
     int gpyx[S2_GPW], gpb[S2_GPW];                                      // (py << 8 | px), or -1 beyond the patch; input-patch byte offset
@@ -238,7 +243,8 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
     };
 
     // ---- stem phase of one tile: input patch -> 9 x 33 pixels of s in this half's LDS patch
-    auto stem_phase = [&](int pk) {
+    auto stem_phase_impl = [&](int pk, auto interior_c) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;         // the whole 9 x 33 patch lies inside the image: no zero-padding selects
         const int x0 = (pk & 1023) * S2_TW, y0 = ((pk >> 10) & 1023) * S2_TH;
         const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;                   // stem pixel of patch (0, 0)
         // the 8 operand dwords of group j + 1 are read while group j computes
@@ -248,7 +254,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             asm volatile("" : "+v"(pb));                                 // (recomputed sums: 40 hoisted addresses would cost 40 VGPRs)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                d[buf][e] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(inp) + (koff[e] < 0 ? S2_IN * 4 : pb + koff[e]));
+                d[buf][e] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(inp) + (pb + koff[e]));
         };
         read_group(0, 0);
 #pragma unroll
@@ -277,7 +283,7 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
                 for (int e = 0; e < 4; ++e) {
                     float v = s[e] * inv0[4 * t + e] + bias0[4 * t + e];
                     v = fmaxf(v, v * slope0);
-                    v = inimg ? v : 0.f;                                 // outside the image: layer 1's zero padding
+                    if constexpr (!INTERIOR) v = inimg ? v : 0.f;       // outside the image: layer 1's zero padding (patch rows past the 297th are never read)
                     _Float16 h, l;
                     split_f16(v, h, l, amax);
                     ph[4 * t + e] = h; pl[4 * t + e] = l;
@@ -288,6 +294,13 @@ void conv_stem2_f16s3_kernel(const Stem2Args a) {
             *reinterpret_cast<f16x8*>(patch + o) = ph;
             *reinterpret_cast<f16x8*>(patch + S2_PLANE + o) = pl;
         }
+    };
+
+    auto stem_phase = [&](int pk) {
+        const int x0 = (pk & 1023) * S2_TW, y0 = ((pk >> 10) & 1023) * S2_TH;
+        const int sy0 = 2 * y0 - 1, sx0 = 2 * x0 - 1;
+        if (sy0 >= 0 && sx0 >= 0 && sy0 + S2_PR <= H && sx0 + S2_PC <= W) stem_phase_impl(pk, std::true_type{});
+        else stem_phase_impl(pk, std::false_type{});
     };
 
     // ---- layer-1 phase of one tile: this wave's output row (ty = wq), 64 channels, + epilogue (+ hosted 1x1 conv)
