@@ -68,7 +68,7 @@ void conv_pwd_f16s3_kernel(const ConvArgs a, const int grid_m, const int grid_n)
     constexpr int NP = BM / 8;                                  // 8-row groups (hi + lo DMA pairs) of a slab
     constexpr int NPP = (NP + NW - 1) / NW;                     // ... per wave: every wave issues the same number (counted waits); a group past
                                                                 // the slab has an out-of-range source and lands in a 4 KiB dump behind the ring
-    static_assert(BM % 16 == 0 && NPP >= 1 && NPP <= 4, "slab pieces per wave");
+    static_assert(BM % 16 == 0 && NPP >= 1 && NPP <= 8, "slab pieces per wave");
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     constexpr int RG = BM * BN * 4 <= 32768 ? BM : (BM / 2) * BN * 4 <= 32768 ? BM / 2 : BM / 4;   // epilogue rows per pass (<= 32 KB of fp32)
     constexpr int WAIT_B = 8 + 2 * NPP;                         // younger than the awaited B set: one B set, one slab, one B set
@@ -239,7 +239,7 @@ static int launch_pwd(const ConvArgs& a, hipStream_t s) {
 // One list drives the mode table, the launch switch and the kernel names rocprofv3 prints:
 //   X(index, BM, waves (BN = 32 waves), ring slabs, MINW)
 #define RTOD_PWD_TILES(X) \
-    X(0, 64, 4, 3, 3) X(1, 32, 4, 3, 3) X(2, 128, 4, 3, 1) X(3, 64, 8, 3, 1) X(4, 64, 4, 2, 3) X(5, 32, 4, 4, 3) X(6, 96, 4, 2, 3) X(7, 96, 4, 3, 2) X(8, 48, 4, 3, 3) X(9, 48, 4, 4, 3)
+    X(0, 64, 4, 3, 3) X(1, 32, 4, 3, 3) X(2, 128, 4, 3, 1) X(3, 64, 8, 3, 1) X(4, 64, 4, 2, 3) X(5, 32, 4, 4, 3) X(6, 96, 4, 2, 3) X(7, 96, 4, 3, 2) X(8, 48, 4, 3, 3) X(9, 48, 4, 4, 3) X(10, 64, 2, 2, 4)
 
 #define RTOD_X_INFO(idx, bm, nw, nst, minw) {bm, nw * 32, "conv_pwd_f16s3<" #bm "x" #nw "w,r" #nst ">"},
 static const ConvVariantInfo kPwdModes[PWD_MODES] = { RTOD_PWD_TILES(RTOD_X_INFO) };

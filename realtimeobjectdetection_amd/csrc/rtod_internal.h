@@ -165,7 +165,7 @@ int launch_conv_ring_f16s3(const ConvArgs& a, int mode, hipStream_t s);
 // 1x1 convolutions with the A operand staged in 64-channel slabs (full-line LDS-DMA) and weight fragments straight from global
 // memory (conv_pwd_f16s3.hip, round 4): same K order and MFMA sequence as the generic / ring tiles -> further autotune candidates
 // of the plain 1x1 layers (no fused decode, no hosted pointwise conv), bit-identical results.
-constexpr int PWD_MODES = 10;
+constexpr int PWD_MODES = 11;
 constexpr int PWD_VARIANT_BASE = 90;       // variant ids in [90, 110): PWD_VARIANT_BASE + mode
 bool conv_pwd_supported(int ksize, int stride, int pad, int cin);
 const ConvVariantInfo& conv_pwd_mode_info(int mode);

@@ -925,7 +925,7 @@ def test_forward_is_capturable_after_autotune(tmp_path_factory):
 def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     """Autotune may pick any tile of a kernel family for a layer, per batch size: every candidate must produce the same
     bits (same K order, same MFMA shape).  Forces each split-f16 tile variant in turn (generic implicit-GEMM tiles 0-11
-    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-67 on the band layers (61-67: conv_bandd_f16s3.hip, weight fragments straight from global memory; 68: its wide tile on the 3x3 layers with 94 < W <= 160), slab tiles 90-99 on the
+    and persistent LDS-DMA ring tiles 70-77 on the non-band layers, band tiles 50-67 on the band layers (61-67: conv_bandd_f16s3.hip, weight fragments straight from global memory; 68: its wide tile on the 3x3 layers with 94 < W <= 160), slab tiles 90-100 on the
     plain 1x1 layers (conv_pwd_f16s3.hip), 2-D patch tiles 110-114 on the wide 3x3 layers) — this also launches every instantiation, including the ones autotune rarely picks."""
     from realtimeobjectdetection_amd.darknet import Darknet
     res = 416
@@ -935,7 +935,7 @@ def test_every_tile_variant_gives_the_same_bits(tmp_path_factory):
     w = synth.synth_weights(O.RefDarknet(cfg_text, res).ir)
     x = torch.from_numpy(synth.synth_frames(2, res)).cuda()
     ref = None
-    for v in list(range(12)) + list(range(50, 70)) + list(range(70, 78)) + list(range(90, 100)) + list(range(110, 115)):
+    for v in list(range(12)) + list(range(50, 70)) + list(range(70, 78)) + list(range(90, 101)) + list(range(110, 115)):
         m = Darknet(cfg_path, True).eval()
         m.net_info["height"] = res
         m.precision = "f16s3"

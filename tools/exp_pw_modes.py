@@ -13,7 +13,7 @@ from realtimeobjectdetection_amd.darknet import Darknet
 out = sys.argv[1]
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 608
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-variants = [int(v) for v in sys.argv[4:]] or [-1, 0, 6, 10, 70, 72, 74, 76] + list(range(90, 100))
+variants = [int(v) for v in sys.argv[4:]] or [-1, 0, 6, 10, 70, 72, 74, 76] + list(range(90, 101))
 text = cfgs.yolov3_cfg(); ir = build_ir(parse_cfg_text(text), res)
 d = tempfile.mkdtemp()
 cfg_path = cfgs.write_cfg(os.path.join(d, "m.cfg"), text)
